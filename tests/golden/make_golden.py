@@ -1,0 +1,129 @@
+"""Generate tests/golden/*.npz from the REFERENCE's own CPU kernels.
+
+Runs only in the build container (needs /root/reference and an AVX-512 host): it
+loads oracle/_ref/vllm_ref_cpu.so -- the reference's csrc/cpu/attention.cpp and
+csrc/cpu/cache.cpp compiled in place by oracle/build_ref.py -- and the reference's
+host-side FNUZ fp8 codec (oracle/_ref/libref_fp8.so), feeds them seeded inputs and
+stores inputs + outputs.  The .npz files are data only; they travel to the GPU box,
+the reference does not.
+
+    python tests/golden/make_golden.py
+"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from oracle import build_ref  # noqa: E402
+
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def bits(t: torch.Tensor) -> np.ndarray:
+    if t.dtype == torch.float32:
+        return t.numpy().copy()
+    return t.view(torch.int16).numpy().view(np.uint16).copy()
+
+
+def attention_case(ref, name, dtype, num_seqs_lens, hq, hkv, d, nb, alibi, seed):
+    g = torch.Generator().manual_seed(seed)
+    bs = 16
+    x = 16 // torch.tensor([], dtype=dtype).element_size()
+    scale = float(d**-0.5)
+    seq_lens = torch.tensor(num_seqs_lens, dtype=torch.int32)
+    s = len(num_seqs_lens)
+    max_len = int(seq_lens.max())
+    mb = (max_len + bs - 1) // bs
+    q = (torch.rand(s, hq, d, generator=g) * 2 - 1).mul(scale).to(dtype)
+    kc = (torch.rand(nb, hkv, d // x, bs, x, generator=g) * 2 - 1).mul(scale).to(dtype)
+    vc = (torch.rand(nb, hkv, d, bs, generator=g) * 2 - 1).mul(scale).to(dtype)
+    bt = torch.randint(0, nb, (s, mb), generator=g, dtype=torch.int32)
+    al = torch.randn(hq, generator=g, dtype=torch.float32) if alibi else None
+    out1 = torch.zeros_like(q)
+    ref.paged_attention_v1(out1, q, kc, vc, hkv, scale, bt, seq_lens, bs, max_len, al, "auto",
+                           1.0, 0, 0, 0, 64, 0)
+    p = (max_len + 511) // 512
+    out2 = torch.zeros_like(q)
+    es = torch.zeros(s, hq, p, dtype=torch.float32)
+    ml = torch.zeros(s, hq, p, dtype=torch.float32)
+    tmp = torch.zeros(s, hq, p, d, dtype=dtype)
+    ref.paged_attention_v2(out2, es, ml, tmp, q, kc, vc, hkv, scale, bt, seq_lens, bs, max_len,
+                           al, "auto", 1.0, 0, 0, 0, 64, 0)
+    np.savez_compressed(
+        os.path.join(OUT, name + ".npz"), dtype=str(dtype).replace("torch.", ""), scale=scale,
+        query=bits(q), key_cache=bits(kc), value_cache=bits(vc), block_tables=bt.numpy(),
+        seq_lens=seq_lens.numpy(), alibi=(al.numpy() if alibi else np.zeros(0, np.float32)),
+        out_v1=bits(out1), out_v2=bits(out2))
+    print(name, "v1/v2 max diff", (out1.float() - out2.float()).abs().max().item())
+
+
+def cache_case(ref, name, dtype, seed):
+    g = torch.Generator().manual_seed(seed)
+    t, h, d, bs, nb = 11, 3, 32, 16, 9
+    x = 16 // torch.tensor([], dtype=dtype).element_size()
+    qkv = torch.randn(t, 3, h, d, generator=g).to(dtype)
+    key, value = qkv[:, 1], qkv[:, 2]  # strided views, as in test_cache.py:137-138
+    kc = torch.randn(nb, h, d // x, bs, x, generator=g).to(dtype)
+    vc = torch.randn(nb, h, d, bs, generator=g).to(dtype)
+    slots = torch.randperm(nb * bs, generator=g)[:t].to(torch.int64)
+    slots[4] = -1  # a padding token
+    kc0, vc0 = kc.clone(), vc.clone()
+    ref.reshape_and_cache(key, value, kc, vc, slots, "auto", 1.0)
+    # copy_blocks on the updated caches: each source to two destinations
+    pairs = torch.tensor([[0, 5], [0, 6], [2, 7], [2, 8]], dtype=torch.int64)
+    kc2, vc2 = kc.clone(), vc.clone()
+    ref.copy_blocks([kc2], [vc2], pairs)
+    np.savez_compressed(
+        os.path.join(OUT, name + ".npz"), dtype=str(dtype).replace("torch.", ""),
+        key=bits(key.contiguous()), value=bits(value.contiguous()), key_cache_in=bits(kc0),
+        value_cache_in=bits(vc0), slot_mapping=slots.numpy(), key_cache_out=bits(kc),
+        value_cache_out=bits(vc), block_mapping=pairs.numpy(), key_cache_copied=bits(kc2),
+        value_cache_copied=bits(vc2))
+    print(name, "done")
+
+
+def fnuz_case():
+    lib = C.CDLL(build_ref.fp8_so_path())
+    lib.ref_fnuz_decode_f32_n.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
+    lib.ref_fnuz_encode_f32_n.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
+    codes = np.arange(256, dtype=np.uint8)
+    dec = np.empty(256, dtype=np.float32)
+    lib.ref_fnuz_decode_f32_n(codes.ctypes.data, dec.ctypes.data, 256)
+    # every finite fp16 value (as float) + edge floats
+    h = np.arange(65536, dtype=np.uint16).view(np.float16).astype(np.float32)
+    h = h[np.isfinite(h)]
+    rng = np.random.default_rng(0)
+    extra = np.concatenate([
+        rng.uniform(-260, 260, 4096).astype(np.float32),
+        (rng.standard_normal(4096) * 0.01).astype(np.float32),
+        np.array([0.0, -0.0, 239.9, 240.0, 244.0, 247.9, 248.0, 1e9, -1e9, np.inf, -np.inf,
+                  np.nan, 2.0**-10, 2.0**-11, 1.5 * 2.0**-11, 2.0**-12], dtype=np.float32)
+    ])
+    x = np.concatenate([h, extra])
+    enc = np.empty(x.size, dtype=np.uint8)
+    lib.ref_fnuz_encode_f32_n(x.ctypes.data, enc.ctypes.data, x.size)
+    np.savez_compressed(os.path.join(OUT, "fp8_fnuz_codec.npz"), decode_table=dec, encode_in=x,
+                        encode_out=enc)
+    print("fnuz codec table done", x.size)
+
+
+def main():
+    assert build_ref.build(), "reference tree not available"
+    ref = build_ref.load_ref()
+    assert ref is not None, "reference CPU kernels need AVX-512 on this host"
+    torch.manual_seed(0)
+    attention_case(ref, "attn_f32_gqa", torch.float32, [1, 37, 600], 8, 2, 64, 16, False, 1)
+    attention_case(ref, "attn_bf16_alibi", torch.bfloat16, [17, 513, 1030], 4, 4, 128, 16, True,
+                   2)
+    attention_case(ref, "attn_f32_d80", torch.float32, [16, 95], 6, 3, 80, 8, False, 3)
+    cache_case(ref, "cache_f32", torch.float32, 4)
+    cache_case(ref, "cache_bf16", torch.bfloat16, 5)
+    fnuz_case()
+
+
+if __name__ == "__main__":
+    main()
