@@ -1,0 +1,168 @@
+/*
+ * C-ABI of the MI355X (gfx950) quantized paged-attention backend.
+ *
+ * One shared library (libvla_gfx950.so) exports these entry points.  They are what a
+ * binding for the reference's `vllm._C` ops on this path would call: plain pointers, sizes,
+ * strides and a HIP stream -- no torch types.  Every function enqueues its work on `stream`
+ * (a hipStream_t passed as void*; NULL = the default stream) and returns immediately; none
+ * of them allocates, frees or synchronises, so all of them may be captured in a HIP graph
+ * (vla_swap_blocks with a host side is the exception, as in the reference).
+ *
+ * Return value: VLA_OK (0) or a VLA_ERR_* code; vla_status_string() gives the text the
+ * reference would have put in its TORCH_CHECK message.  A non-zero status means nothing was
+ * launched.
+ *
+ * Citations are paths in the reference tree (DeepAuto-AI/vllm-legacy).
+ */
+#ifndef VLA_PAGED_ATTENTION_H_
+#define VLA_PAGED_ATTENTION_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* model ("scalar") dtypes */
+#define VLA_F16 0
+#define VLA_BF16 1
+#define VLA_F32 2
+
+/* KV-cache dtypes: "auto" = the model dtype; "fp8" / "fp8_e4m3" = OCP e4m3fn bytes with one
+ * fp32 scale per call (quantise: fp8(x / kv_scale), dequantise: fp8 * kv_scale). */
+#define VLA_KV_AUTO 0
+#define VLA_KV_FP8_E4M3 1
+
+#define VLA_OK 0
+#define VLA_ERR_HEAD_SIZE 1    /* "Unsupported head size"   attention_kernels.cu:763-765 */
+#define VLA_ERR_BLOCK_SIZE 2   /* "Unsupported block size"  attention_kernels.cu:800-802 */
+#define VLA_ERR_DTYPE 3        /* "Unsupported input type of kv cache" amd/quant_utils.cuh:553 */
+#define VLA_ERR_KV_DTYPE 4     /* "Unsupported data type of kv cache"  amd/quant_utils.cuh:569 */
+#define VLA_ERR_ARG 5          /* inconsistent sizes / null pointers */
+#define VLA_ERR_BLOCKSPARSE 6  /* blocksparse_vert_stride > 1 is not implemented */
+#define VLA_ERR_HIP 7          /* a HIP runtime call failed (see vla_last_hip_error) */
+#define VLA_ERR_QUANT_SHAPE 8  /* AWQ/GPTQ shape constraint, gemm_kernels.cu:515-522 */
+
+#define VLA_PARTITION_SIZE 512 /* attention_kernels.cu:846, vllm/attention/ops/paged_attn.py:10 */
+
+const char* vla_status_string(int status);
+int vla_last_hip_error(void);            /* hipError_t of the last VLA_ERR_HIP on this thread */
+int vla_abi_version(void);
+/* Test hook, no counterpart in the reference: 0 = choose the attention kernel per shape
+ * (default), 1 = always run the generic kernel. Process-wide. */
+int vla_set_attention_path(int mode);
+/* "auto" -> VLA_KV_AUTO, "fp8" / "fp8_e4m3" -> VLA_KV_FP8_E4M3, anything else -> -1
+ * (DISPATCH_BY_KV_CACHE_DTYPE, csrc/quantization/fp8/amd/quant_utils.cuh:545-571). */
+int vla_kv_dtype_from_string(const char* name);
+
+/* Replaces paged_attention_v1 (csrc/ops.h:5-12; csrc/attention/attention_kernels.cu:805-825).
+ *   out, query   [num_seqs, num_heads, head_size] model dtype; query row stride q_stride
+ *                (elements), out contiguous
+ *   key_cache    [num_blocks, num_kv_heads, head_size/x, block_size, x], x = 16 / sizeof(cache
+ *                element); value_cache [num_blocks, num_kv_heads, head_size, block_size]
+ *   kv_block_stride, kv_head_stride: elements, shared by both caches (:706-707)
+ *   block_tables [num_seqs, max_num_blocks_per_seq] int32; seq_lens [num_seqs] int32
+ *   alibi_slopes [num_heads] fp32 or NULL
+ * head_size in {64,80,96,112,128,192,256}, block_size in {8,16,32}. */
+int vla_paged_attention_v1(void* out, const void* query, const void* key_cache,
+                           const void* value_cache, int num_seqs, int num_heads,
+                           int num_kv_heads, int head_size, int block_size, float scale,
+                           const int* block_tables, const int* seq_lens,
+                           int max_num_blocks_per_seq, int max_seq_len,
+                           const float* alibi_slopes, int64_t q_stride, int64_t kv_block_stride,
+                           int64_t kv_head_stride, int dtype, int kv_dtype, float kv_scale,
+                           int tp_rank, int blocksparse_local_blocks,
+                           int blocksparse_vert_stride, int blocksparse_block_size,
+                           int blocksparse_head_sliding_step, void* stream);
+
+/* Replaces paged_attention_v2 (csrc/ops.h:14-30; attention_kernels.cu:984-1014) including its
+ * reduce kernel (:567-669).  Caller-owned scratch, P = ceil(max_seq_len / 512):
+ *   exp_sums, max_logits [num_seqs, num_heads, P] fp32; tmp_out [num_seqs, num_heads, P,
+ *   head_size] model dtype.  The fork passes the caches as decimal pointer strings plus
+ *   stride(0)/stride(1) (csrc/ops.h:21-24); here they are the pointers and strides themselves. */
+int vla_paged_attention_v2(void* out, float* exp_sums, float* max_logits, void* tmp_out,
+                           const void* query, const void* key_cache, const void* value_cache,
+                           int num_seqs, int num_heads, int num_kv_heads, int head_size,
+                           int block_size, float scale, const int* block_tables,
+                           const int* seq_lens, int max_num_blocks_per_seq, int max_seq_len,
+                           const float* alibi_slopes, int64_t q_stride, int64_t kv_block_stride,
+                           int64_t kv_head_stride, int dtype, int kv_dtype, float kv_scale,
+                           int tp_rank, int blocksparse_local_blocks,
+                           int blocksparse_vert_stride, int blocksparse_block_size,
+                           int blocksparse_head_sliding_step, void* stream);
+
+/* Replaces reshape_and_cache (csrc/cache.h:15-25; csrc/cache_kernels.cu:251-287).
+ *   key, value [num_tokens, num_heads, head_size] model dtype, token strides in elements;
+ *   slot_mapping [num_tokens] int64, negative = padding (skipped). */
+int vla_reshape_and_cache(const void* key, const void* value, void* key_cache,
+                          void* value_cache, const int64_t* slot_mapping, int num_tokens,
+                          int num_heads, int head_size, int block_size, int x,
+                          int64_t key_stride, int64_t value_stride, int dtype, int kv_dtype,
+                          float kv_scale, void* stream);
+
+/* Replaces copy_blocks (csrc/cache.h:11-13; csrc/cache_kernels.cu:99-146).
+ *   key_caches, value_caches: HOST arrays of num_layers device pointers;
+ *   block_mapping: DEVICE int64 [num_pairs, 2] (src, dst); block_bytes = bytes of one block of
+ *   one cache.  The pointer tables travel as kernel arguments: no allocation, no host sync
+ *   (the reference does a synchronous H2D copy, :124-131). */
+int vla_copy_blocks(void* const* key_caches, void* const* value_caches, int num_layers,
+                    const int64_t* block_mapping, int num_pairs, int64_t block_bytes,
+                    void* stream);
+
+/* Replaces swap_blocks (csrc/cache.h:8-9; csrc/cache_kernels.cu:25-64).
+ *   block_mapping: HOST int64 [num_pairs, 2]; direction: 0 = device->device (same GPU),
+ *   1 = device->host, 2 = host->device.  Runs of consecutive (src, dst) pairs are merged into
+ *   one hipMemcpyAsync each. */
+#define VLA_SWAP_D2D 0
+#define VLA_SWAP_D2H 1
+#define VLA_SWAP_H2D 2
+int vla_swap_blocks(const void* src, void* dst, const int64_t* block_mapping, int num_pairs,
+                    int64_t block_bytes, int direction, void* stream);
+
+/* Replaces convert_fp8 (csrc/cache.h:41-42; csrc/cache_kernels.cu:370-420): n elements,
+ * to_fp8 != 0: model dtype -> fp8(x / scale); else fp8 -> model dtype (fp8 * scale). */
+int vla_convert_fp8(void* dst, const void* src, int64_t n, int dtype, int kv_dtype,
+                    float scale, int to_fp8, void* stream);
+
+/* Replaces awq_dequantize (csrc/ops.h:73-76; csrc/quantization/awq/gemm_kernels.cu:436-484).
+ *   qweight [in_c, out_c/8] int32, scales [in_c/group, out_c] fp16, qzeros [in_c/group,
+ *   out_c/8] int32 -> out [in_c, out_c] fp16. */
+int vla_awq_dequantize(const int32_t* qweight, const void* scales, const int32_t* qzeros,
+                       void* out, int in_c, int out_c, int group, void* stream);
+
+/* Replaces awq_gemm (csrc/ops.h:69-71; gemm_kernels.cu:492-549): out[M, out_c] = x[M, in_c] .
+ * dequant(qweight), fp16 in/out, fp32 accumulate, one rounding (no split-K partial sums). */
+int vla_awq_gemm(const void* x, const int32_t* qweight, const void* scales,
+                 const int32_t* qzeros, void* out, int m, int in_c, int out_c, int group,
+                 void* stream);
+
+/* Replaces the dequantisation inside gptq_gemm (csrc/quantization/gptq/q_gemm.cu:856-959,
+ * :1386-1420), 4 bit: qweight [K/8, N] int32, qzeros [groups, N/8] int32, scales [groups, N]
+ * fp16, g_idx [K] int32 or NULL (group = k / (K/groups)); shuffled != 0: qweight is in the
+ * order written by vla_gptq_shuffle.  out [K, N] fp16. */
+int vla_gptq_dequantize(const int32_t* qweight, const int32_t* qzeros, const void* scales,
+                        const int32_t* g_idx, void* out, int size_k, int size_n, int groups,
+                        int shuffled, void* stream);
+
+/* Replaces gptq_gemm (csrc/ops.h:111-114; q_gemm.cu:1823-1846), 4 bit only.
+ *   use_exllama != 0: qweight was shuffled and b_g_idx (nullable) is the column permutation
+ *   applied to `a` (q_gemm.cu:224-227); use_exllama == 0: plain GPTQ layout, b_g_idx maps
+ *   k -> group (q_gemm.cu:1410-1412). */
+int vla_gptq_gemm(const void* a, const int32_t* qweight, const int32_t* qzeros,
+                  const void* scales, const int32_t* b_g_idx, void* out, int m, int size_n,
+                  int size_k, int groups, int use_exllama, int bit, void* stream);
+
+/* Replaces gptq_shuffle (csrc/ops.h:116; q_gemm.cu:1848-1856), 4 bit, in place.
+ *   q_perm [K] int32 or NULL; scratch: device buffer of K/8 * N int32, needed only when q_perm
+ *   is given (the reference cudaMalloc's it, q_gemm.cu:1774-1775). */
+int vla_gptq_shuffle(int32_t* qweight, const int32_t* q_perm, int32_t* scratch, int size_k,
+                     int size_n, int bit, void* stream);
+
+/* Replaces get_max_shared_memory_per_block_device_attribute
+ * (csrc/cuda_utils_kernels.cu:17-29). Returns bytes, or -1. */
+int vla_get_max_shared_memory_per_block(int device);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VLA_PAGED_ATTENTION_H_ */

@@ -1,0 +1,156 @@
+"""GPU parity tests for the int4 weight path (AWQ / GPTQ dequantise, exllama shuffle, dequant-GEMM).
+
+The reference has no kernel-level test for these ops (only Marlin, tests/kernels/test_marlin_gemm.py)
+and AWQ has no ROCm build at all, so kernel-level parity is pinned by the oracle's restatement of
+the CUDA sources: dequantised weights and the shuffle are compared bit for bit; GEMM outputs within
+fp16 accumulation-order tolerance ("parity unpinned" against any reference binary).
+Weight recipes follow vllm/model_executor/layers/quantization/utils/quant_utils.py:39-146.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as O
+from tests import pa_testlib as T
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from vllm_legacy_amd import _custom_ops
+    return _custom_ops
+
+
+def _awq_weights(rng, ic, oc, group):
+    qweight = rng.integers(-2**31, 2**31, (ic, oc // 8), dtype=np.int64).astype(np.int32)
+    qzeros = rng.integers(-2**31, 2**31, (ic // group, oc // 8), dtype=np.int64).astype(np.int32)
+    scales = O.to_bits((rng.uniform(0.5, 1.5, (ic // group, oc)) * 1e-2).astype(np.float32), O.DT_F16)
+    return qweight, qzeros, scales
+
+
+def _gptq_weights(rng, k, n, group):
+    qweight = rng.integers(-2**31, 2**31, (k // 8, n), dtype=np.int64).astype(np.int32)
+    qzeros = rng.integers(-2**31, 2**31, (k // group, n // 8), dtype=np.int64).astype(np.int32)
+    scales = O.to_bits((rng.uniform(0.5, 1.5, (k // group, n)) * 1e-2).astype(np.float32), O.DT_F16)
+    return qweight, qzeros, scales
+
+
+def _cuda(a, dt=None):
+    if dt is not None:
+        return T.from_bits(a, dt, "cuda")
+    return torch.from_numpy(a).cuda()
+
+
+@pytest.mark.parametrize("ic,oc,group", [(256, 512, 128), (128, 64, 32), (4096, 6144, 128)])
+def test_awq_dequantize_bit_exact(ops, ic, oc, group):
+    rng = np.random.default_rng(ic + oc)
+    qw, qz, sc = _awq_weights(rng, ic, oc, group)
+    got = ops.awq_dequantize(_cuda(qw), _cuda(sc, O.DT_F16), _cuda(qz), 0, 0, 0)
+    torch.cuda.synchronize()
+    assert got.shape == (ic, oc) and got.dtype == torch.float16
+    assert np.array_equal(T.bits(got), O.awq_dequantize(qw, sc, qz))
+
+
+@pytest.mark.parametrize("k,n,group", [(256, 512, 128), (128, 64, 32), (4096, 1280, 128)])
+@pytest.mark.parametrize("act_order", [False, True])
+def test_gptq_dequantize_bit_exact(ops, k, n, group, act_order):
+    rng = np.random.default_rng(k + n)
+    qw, qz, sc = _gptq_weights(rng, k, n, group)
+    g_idx = None
+    if act_order:
+        g_idx = rng.permutation(np.arange(k) // group).astype(np.int32)
+    got = ops.gptq_dequantize(_cuda(qw), _cuda(qz), _cuda(sc, O.DT_F16),
+                              None if g_idx is None else _cuda(g_idx))
+    torch.cuda.synchronize()
+    assert np.array_equal(T.bits(got), O.gptq_dequantize(qw, qz, sc, g_idx))
+
+
+@pytest.mark.parametrize("with_perm", [False, True])
+def test_gptq_shuffle_bit_exact_and_dequant_consistent(ops, with_perm):
+    rng = np.random.default_rng(7)
+    k, n, group = 512, 256, 128
+    qw, qz, sc = _gptq_weights(rng, k, n, group)
+    perm = rng.permutation(k).astype(np.int32) if with_perm else None
+    t_qw = _cuda(qw.copy())
+    ops.gptq_shuffle(t_qw, torch.empty(0, dtype=torch.int32, device="cuda") if perm is None
+                     else _cuda(perm), 4)
+    torch.cuda.synchronize()
+    want = O.gptq_shuffle(qw, perm)
+    assert np.array_equal(t_qw.cpu().numpy(), want)
+    if not with_perm:
+        # dequantising the shuffled words gives the same matrix as the plain ones
+        a = ops.gptq_dequantize(t_qw, _cuda(qz), _cuda(sc, O.DT_F16), None, shuffled=True)
+        torch.cuda.synchronize()
+        assert np.array_equal(T.bits(a), O.gptq_dequantize(qw, qz, sc))
+
+
+def _gemm_close(got: torch.Tensor, want_bits: np.ndarray):
+    g = got.float().cpu().numpy()
+    w = O.from_bits(want_bits, O.DT_F16)
+    # both sides accumulate in fp32 and round once to fp16; only the summation order differs
+    np.testing.assert_allclose(g, w, rtol=2e-3, atol=4e-3)
+
+
+@pytest.mark.parametrize("m", [1, 7, 16, 50, 256, 300])
+@pytest.mark.parametrize("ic,oc,group", [(512, 256, 128), (4096, 4096, 128)])
+def test_awq_gemm(ops, m, ic, oc, group):
+    if ic == 4096 and m not in (1, 256):
+        pytest.skip("large shape only at the two batch sizes that matter")
+    rng = np.random.default_rng(m + ic)
+    qw, qz, sc = _awq_weights(rng, ic, oc, group)
+    x = O.to_bits(rng.uniform(-1, 1, (m, ic)).astype(np.float32), O.DT_F16)
+    got = ops.awq_gemm(_cuda(x, O.DT_F16), _cuda(qw), _cuda(sc, O.DT_F16), _cuda(qz), 8)
+    torch.cuda.synchronize()
+    _gemm_close(got, O.gemm_f16(x, O.awq_dequantize(qw, sc, qz)))
+
+
+@pytest.mark.parametrize("m", [1, 8, 51, 256])
+@pytest.mark.parametrize("mode", ["plain", "plain_gidx", "exllama", "exllama_perm"])
+def test_gptq_gemm(ops, m, mode):
+    rng = np.random.default_rng(m)
+    k, n, group = 1024, 512, 128
+    qw, qz, sc = _gptq_weights(rng, k, n, group)
+    x = O.to_bits(rng.uniform(-1, 1, (m, k)).astype(np.float32), O.DT_F16)
+    empty = torch.empty(0, dtype=torch.int32, device="cuda")
+    if mode == "plain":
+        got = ops.gptq_gemm(_cuda(x, O.DT_F16), _cuda(qw), _cuda(qz), _cuda(sc, O.DT_F16), empty,
+                            False, 4)
+        want = O.gemm_f16(x, O.gptq_dequantize(qw, qz, sc))
+    elif mode == "plain_gidx":
+        g_idx = rng.permutation(np.arange(k) // group).astype(np.int32)
+        got = ops.gptq_gemm(_cuda(x, O.DT_F16), _cuda(qw), _cuda(qz), _cuda(sc, O.DT_F16),
+                            _cuda(g_idx), False, 4)
+        want = O.gemm_f16(x, O.gptq_dequantize(qw, qz, sc, g_idx))
+    elif mode == "exllama":
+        t_qw = _cuda(qw.copy())
+        ops.gptq_shuffle(t_qw, empty, 4)
+        got = ops.gptq_gemm(_cuda(x, O.DT_F16), t_qw, _cuda(qz), _cuda(sc, O.DT_F16), empty, True, 4)
+        want = O.gemm_f16(x, O.gptq_dequantize(qw, qz, sc))
+    else:
+        # act-order through exllama: rows sorted by group (q_perm = argsort(g_idx),
+        # quantization/gptq.py:209-217), activations gathered by the same permutation
+        g_idx = rng.permutation(np.arange(k) // group).astype(np.int32)
+        perm = np.argsort(g_idx, kind="stable").astype(np.int32)
+        t_qw = _cuda(qw.copy())
+        ops.gptq_shuffle(t_qw, _cuda(perm), 4)
+        got = ops.gptq_gemm(_cuda(x, O.DT_F16), t_qw, _cuda(qz), _cuda(sc, O.DT_F16), _cuda(perm),
+                            True, 4)
+        want = O.gemm_f16(x, O.gptq_dequantize(qw, qz, sc, g_idx))
+    torch.cuda.synchronize()
+    _gemm_close(got, want)
+
+
+def test_quant_shape_errors(ops):
+    z = torch.zeros
+    with pytest.raises(RuntimeError, match="Unsupported quantized weight shape"):
+        ops.awq_gemm(z((4, 128), dtype=torch.float16, device="cuda"),
+                     z((128, 4), dtype=torch.int32, device="cuda"),       # OC = 32: not % 64
+                     z((1, 32), dtype=torch.float16, device="cuda"),
+                     z((1, 4), dtype=torch.int32, device="cuda"), 8)
+    with pytest.raises(RuntimeError, match="Unsupported quantized weight shape"):
+        ops.gptq_gemm(z((4, 128), dtype=torch.float16, device="cuda"),
+                      z((16, 64), dtype=torch.int32, device="cuda"),
+                      z((1, 8), dtype=torch.int32, device="cuda"),
+                      z((1, 64), dtype=torch.float16, device="cuda"),
+                      torch.empty(0, dtype=torch.int32, device="cuda"), True, 8)  # 8-bit

@@ -1,0 +1,349 @@
+"""Drop-in for the hot-path part of the reference's `vllm._custom_ops`.
+
+Same function names, argument order and in-place/return conventions as
+vllm/_custom_ops.py:37-99 (paged attention), :138-161 (AWQ / GPTQ) and :304-354 (cache ops),
+bound to the gfx950 C-ABI library instead of `vllm._C`.  Tensors stay torch tensors; only raw
+pointers, sizes and the current HIP stream cross into the library.
+
+The KV caches may be torch tensors or any object with `data_ptr()`, `stride(i)` and `size(i)`
+(the fork's managed-memory cache objects, vllm/worker/cache_engine/map_cache_engine.py:35-66),
+which is why the fork passes them to `vllm._C` as pointer strings; `vllm_legacy_amd._C` offers
+that pointer-string form too.
+"""
+import ctypes as C
+from typing import List, Optional
+
+import torch
+
+from . import _lib
+from ._lib import check
+
+_DTYPE = {torch.float16: _lib.F16, torch.bfloat16: _lib.BF16, torch.float32: _lib.F32}
+
+
+def _dt(t: torch.Tensor) -> int:
+    try:
+        return _DTYPE[t.dtype]
+    except KeyError:
+        raise RuntimeError(f"Unsupported input type of kv cache: {t.dtype}") from None
+
+
+def _stream(device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def _ptr(t) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _require_cuda(*ts):
+    for t in ts:
+        if t is not None and isinstance(t, torch.Tensor) and not t.is_cuda:
+            raise RuntimeError("expected a tensor on the GPU")
+
+
+# ---------------------------------------------------------------- paged attention
+
+
+def paged_attention_v1(
+    out: torch.Tensor,
+    query: torch.Tensor,
+    key_cache,
+    value_cache,
+    num_kv_heads: int,
+    scale: float,
+    block_tables: torch.Tensor,
+    seq_lens: torch.Tensor,
+    block_size: int,
+    max_seq_len: int,
+    alibi_slopes: Optional[torch.Tensor],
+    kv_cache_dtype: str,
+    kv_scale: float,
+    tp_rank: int = 0,
+    blocksparse_local_blocks: int = 0,
+    blocksparse_vert_stride: int = 0,
+    blocksparse_block_size: int = 64,
+    blocksparse_head_sliding_step: int = 0,
+) -> None:
+    paged_attention_v1_raw(out, query, key_cache.data_ptr(), key_cache.stride(0),
+                           key_cache.stride(1), value_cache.data_ptr(), num_kv_heads, scale,
+                           block_tables, seq_lens, block_size, max_seq_len, alibi_slopes,
+                           kv_cache_dtype, kv_scale, tp_rank, blocksparse_local_blocks,
+                           blocksparse_vert_stride, blocksparse_block_size,
+                           blocksparse_head_sliding_step)
+
+
+def paged_attention_v1_raw(out, query, key_cache_ptr: int, kv_block_stride: int,
+                           kv_head_stride: int, value_cache_ptr: int, num_kv_heads, scale,
+                           block_tables, seq_lens, block_size, max_seq_len, alibi_slopes,
+                           kv_cache_dtype, kv_scale, tp_rank=0, blocksparse_local_blocks=0,
+                           blocksparse_vert_stride=0, blocksparse_block_size=64,
+                           blocksparse_head_sliding_step=0) -> None:
+    _require_cuda(out, query, block_tables, seq_lens, alibi_slopes)
+    num_seqs, num_heads, head_size = query.shape
+    assert out.is_contiguous() and query.stride(1) == head_size and query.stride(2) == 1
+    assert block_tables.dtype == torch.int32 and seq_lens.dtype == torch.int32
+    assert block_tables.stride(1) == 1
+    with torch.cuda.device(query.device):
+        check(_lib.lib().vla_paged_attention_v1(
+            out.data_ptr(), query.data_ptr(), key_cache_ptr, value_cache_ptr, num_seqs, num_heads,
+            num_kv_heads, head_size, block_size, scale, block_tables.data_ptr(),
+            seq_lens.data_ptr(), block_tables.stride(0), max_seq_len, _ptr(alibi_slopes),
+            query.stride(0), kv_block_stride, kv_head_stride, _dt(query),
+            _lib.kv_dtype_code(kv_cache_dtype), kv_scale, tp_rank, blocksparse_local_blocks,
+            blocksparse_vert_stride, blocksparse_block_size, blocksparse_head_sliding_step,
+            _stream(query.device)), "paged_attention_v1")
+
+
+def paged_attention_v2(
+    out: torch.Tensor,
+    exp_sum: torch.Tensor,
+    max_logits: torch.Tensor,
+    tmp_out: torch.Tensor,
+    query: torch.Tensor,
+    key_cache,
+    value_cache,
+    num_kv_heads: int,
+    scale: float,
+    block_tables: torch.Tensor,
+    seq_lens: torch.Tensor,
+    block_size: int,
+    max_seq_len: int,
+    alibi_slopes: Optional[torch.Tensor],
+    kv_cache_dtype: str,
+    kv_scale: float,
+    tp_rank: int = 0,
+    blocksparse_local_blocks: int = 0,
+    blocksparse_vert_stride: int = 0,
+    blocksparse_block_size: int = 64,
+    blocksparse_head_sliding_step: int = 0,
+) -> None:
+    paged_attention_v2_raw(out, exp_sum, max_logits, tmp_out, query, key_cache.data_ptr(),
+                           key_cache.stride(0), key_cache.stride(1), value_cache.data_ptr(),
+                           num_kv_heads, scale, block_tables, seq_lens, block_size, max_seq_len,
+                           alibi_slopes, kv_cache_dtype, kv_scale, tp_rank,
+                           blocksparse_local_blocks, blocksparse_vert_stride,
+                           blocksparse_block_size, blocksparse_head_sliding_step)
+
+
+def paged_attention_v2_raw(out, exp_sum, max_logits, tmp_out, query, key_cache_ptr: int,
+                           kv_block_stride: int, kv_head_stride: int, value_cache_ptr: int,
+                           num_kv_heads, scale, block_tables, seq_lens, block_size, max_seq_len,
+                           alibi_slopes, kv_cache_dtype, kv_scale, tp_rank=0,
+                           blocksparse_local_blocks=0, blocksparse_vert_stride=0,
+                           blocksparse_block_size=64, blocksparse_head_sliding_step=0) -> None:
+    _require_cuda(out, exp_sum, max_logits, tmp_out, query, block_tables, seq_lens, alibi_slopes)
+    num_seqs, num_heads, head_size = query.shape
+    num_partitions = (max_seq_len + _lib.PARTITION_SIZE - 1) // _lib.PARTITION_SIZE
+    assert out.is_contiguous() and query.stride(1) == head_size and query.stride(2) == 1
+    assert exp_sum.is_contiguous() and max_logits.is_contiguous() and tmp_out.is_contiguous()
+    assert exp_sum.dtype == torch.float32 and max_logits.dtype == torch.float32
+    assert tuple(exp_sum.shape) == (num_seqs, num_heads, num_partitions), \
+        "exp_sums must be [num_seqs, num_heads, ceil(max_seq_len / 512)]"
+    assert tuple(tmp_out.shape) == (num_seqs, num_heads, num_partitions, head_size)
+    assert block_tables.dtype == torch.int32 and seq_lens.dtype == torch.int32
+    assert block_tables.stride(1) == 1
+    with torch.cuda.device(query.device):
+        check(_lib.lib().vla_paged_attention_v2(
+            out.data_ptr(), exp_sum.data_ptr(), max_logits.data_ptr(), tmp_out.data_ptr(),
+            query.data_ptr(), key_cache_ptr, value_cache_ptr, num_seqs, num_heads, num_kv_heads,
+            head_size, block_size, scale, block_tables.data_ptr(), seq_lens.data_ptr(),
+            block_tables.stride(0), max_seq_len, _ptr(alibi_slopes), query.stride(0),
+            kv_block_stride, kv_head_stride, _dt(query), _lib.kv_dtype_code(kv_cache_dtype),
+            kv_scale, tp_rank, blocksparse_local_blocks, blocksparse_vert_stride,
+            blocksparse_block_size, blocksparse_head_sliding_step, _stream(query.device)),
+            "paged_attention_v2")
+
+
+# ---------------------------------------------------------------- cache ops
+
+
+def reshape_and_cache(
+    key: torch.Tensor,
+    value: torch.Tensor,
+    key_cache,
+    value_cache,
+    slot_mapping: torch.Tensor,
+    kv_cache_dtype: str,
+    kv_scale: float,
+) -> None:
+    reshape_and_cache_raw(key, value, key_cache.data_ptr(), key_cache.size(3), key_cache.size(4),
+                          value_cache.data_ptr(), slot_mapping, kv_cache_dtype, kv_scale)
+
+
+def reshape_and_cache_raw(key, value, key_cache_ptr: int, block_size: int, x: int,
+                          value_cache_ptr: int, slot_mapping, kv_cache_dtype, kv_scale) -> None:
+    _require_cuda(key, value, slot_mapping)
+    num_tokens, num_heads, head_size = key.shape
+    assert key.stride(1) == head_size and key.stride(2) == 1
+    assert value.stride(1) == head_size and value.stride(2) == 1
+    assert slot_mapping.dtype == torch.int64 and slot_mapping.is_contiguous()
+    assert slot_mapping.numel() >= num_tokens
+    with torch.cuda.device(key.device):
+        check(_lib.lib().vla_reshape_and_cache(
+            key.data_ptr(), value.data_ptr(), key_cache_ptr, value_cache_ptr,
+            slot_mapping.data_ptr(), num_tokens, num_heads, head_size, block_size, x,
+            key.stride(0), value.stride(0), _dt(key), _lib.kv_dtype_code(kv_cache_dtype),
+            kv_scale, _stream(key.device)), "reshape_and_cache")
+
+
+def copy_blocks(key_caches: List[torch.Tensor], value_caches: List[torch.Tensor],
+                block_mapping: torch.Tensor) -> None:
+    num_layers = len(key_caches)
+    if num_layers != len(value_caches):
+        raise RuntimeError("key_caches and value_caches must have the same length")
+    if num_layers == 0:
+        return
+    dev = key_caches[0].device
+    if not key_caches[0].is_cuda:
+        raise RuntimeError("copy_blocks: caches must be on the GPU")
+    assert block_mapping.is_cuda and block_mapping.dtype == torch.int64
+    bm = block_mapping.contiguous().view(-1, 2)
+    block_bytes = key_caches[0][0].numel() * key_caches[0].element_size()
+    kp = (C.c_void_p * num_layers)(*[t.data_ptr() for t in key_caches])
+    vp = (C.c_void_p * num_layers)(*[t.data_ptr() for t in value_caches])
+    with torch.cuda.device(dev):
+        check(_lib.lib().vla_copy_blocks(kp, vp, num_layers, bm.data_ptr(), bm.shape[0],
+                                         block_bytes, _stream(dev)), "copy_blocks")
+
+
+def swap_blocks(src: torch.Tensor, dst: torch.Tensor, block_mapping: torch.Tensor) -> None:
+    if src.is_cuda and dst.is_cuda:
+        if src.device != dst.device:
+            raise RuntimeError("src and dst must be on the same GPU")
+        direction, dev = _lib.SWAP_D2D, src.device
+    elif src.is_cuda and not dst.is_cuda:
+        direction, dev = _lib.SWAP_D2H, src.device
+    elif not src.is_cuda and dst.is_cuda:
+        direction, dev = _lib.SWAP_H2D, dst.device
+    else:
+        raise RuntimeError("Invalid device combination")
+    if block_mapping.is_cuda:
+        raise RuntimeError("block_mapping must be on CPU")
+    bm = block_mapping.to(torch.int64).contiguous().view(-1, 2)
+    assert src.is_contiguous() and dst.is_contiguous()
+    block_bytes = src[0].numel() * src.element_size()
+    with torch.cuda.device(dev):
+        check(_lib.lib().vla_swap_blocks(src.data_ptr(), dst.data_ptr(), bm.data_ptr(),
+                                         bm.shape[0], block_bytes, direction, _stream(dev)),
+              "swap_blocks")
+
+
+def convert_fp8(output: torch.Tensor, input: torch.Tensor, scale: float = 1.0,
+                kv_dtype: str = "fp8") -> None:
+    _require_cuda(output, input)
+    if output.device != input.device:
+        raise RuntimeError("src and dst must be on the same GPU")
+    assert output.is_contiguous() and input.is_contiguous() and output.numel() == input.numel()
+    if input.dtype == torch.uint8 and output.dtype != torch.uint8:
+        to_fp8, dt = 0, _dt(output)
+    elif output.dtype == torch.uint8 and input.dtype != torch.uint8:
+        to_fp8, dt = 1, _dt(input)
+    else:
+        raise RuntimeError("convert_fp8 needs exactly one uint8 side")
+    with torch.cuda.device(input.device):
+        check(_lib.lib().vla_convert_fp8(output.data_ptr(), input.data_ptr(), input.numel(), dt,
+                                         _lib.kv_dtype_code(kv_dtype), scale, to_fp8,
+                                         _stream(input.device)), "convert_fp8")
+
+
+# ---------------------------------------------------------------- int4 weights
+
+
+def awq_dequantize(qweight: torch.Tensor, scales: torch.Tensor, zeros: torch.Tensor,
+                   split_k_iters: int = 0, thx: int = 0, thy: int = 0) -> torch.Tensor:
+    """[in_c, out_c] fp16. split_k_iters / thx / thy only shape the reference's launch
+    (csrc/quantization/awq/gemm_kernels.cu:445-461) and are accepted and ignored."""
+    _require_cuda(qweight, scales, zeros)
+    assert qweight.dtype == torch.int32 and zeros.dtype == torch.int32
+    assert scales.dtype == torch.float16 and qweight.is_contiguous() and scales.is_contiguous()
+    in_c, qoc = qweight.shape
+    out = torch.empty((in_c, qoc * 8), dtype=scales.dtype, device=scales.device)
+    with torch.cuda.device(scales.device):
+        check(_lib.lib().vla_awq_dequantize(qweight.data_ptr(), scales.data_ptr(),
+                                            zeros.data_ptr(), out.data_ptr(), in_c, qoc * 8,
+                                            in_c // scales.shape[0], _stream(scales.device)),
+              "awq_dequantize")
+    return out
+
+
+def awq_gemm(input: torch.Tensor, qweight: torch.Tensor, scales: torch.Tensor,
+             qzeros: torch.Tensor, split_k_iters: int = 8) -> torch.Tensor:
+    """Positional order is (x, qweight, scales, qzeros, split_k_iters) as in csrc/ops.h:69-71
+    (the reference wrapper's parameter names are swapped, vllm/_custom_ops.py:145-147, its
+    caller passes scales third, quantization/awq.py:171).  Split-K is not needed here: the
+    contraction is accumulated in fp32 in one pass, so `split_k_iters` is ignored."""
+    _require_cuda(input, qweight, scales, qzeros)
+    assert input.dtype == torch.float16 and scales.dtype == torch.float16
+    assert qweight.dtype == torch.int32 and qzeros.dtype == torch.int32
+    x = input.contiguous()
+    m, in_c = x.shape
+    out_c = qweight.shape[1] * 8
+    out = torch.empty((m, out_c), dtype=x.dtype, device=x.device)
+    with torch.cuda.device(x.device):
+        check(_lib.lib().vla_awq_gemm(x.data_ptr(), qweight.data_ptr(), scales.data_ptr(),
+                                      qzeros.data_ptr(), out.data_ptr(), m, in_c, out_c,
+                                      in_c // scales.shape[0], _stream(x.device)), "awq_gemm")
+    return out
+
+
+def gptq_gemm(a: torch.Tensor, b_q_weight: torch.Tensor, b_gptq_qzeros: torch.Tensor,
+              b_gptq_scales: torch.Tensor, b_g_idx: torch.Tensor, use_exllama: bool,
+              bit: int) -> torch.Tensor:
+    _require_cuda(a, b_q_weight, b_gptq_qzeros, b_gptq_scales)
+    assert a.dtype == torch.float16 and b_gptq_scales.dtype == torch.float16
+    x = a.contiguous()
+    m, k = x.shape
+    n = b_q_weight.shape[1]
+    out = torch.empty((m, n), dtype=x.dtype, device=x.device)
+    gidx = None
+    if b_g_idx is not None and b_g_idx.device.type != "meta" and b_g_idx.numel() > 0:
+        assert b_g_idx.dtype == torch.int32 and b_g_idx.is_cuda
+        gidx = b_g_idx
+    with torch.cuda.device(x.device):
+        check(_lib.lib().vla_gptq_gemm(x.data_ptr(), b_q_weight.data_ptr(),
+                                       b_gptq_qzeros.data_ptr(), b_gptq_scales.data_ptr(),
+                                       _ptr(gidx), out.data_ptr(), m, n, k,
+                                       b_gptq_qzeros.shape[0], 1 if use_exllama else 0, bit,
+                                       _stream(x.device)), "gptq_gemm")
+    return out
+
+
+def gptq_shuffle(q_weight: torch.Tensor, q_perm: torch.Tensor, bit: int) -> None:
+    _require_cuda(q_weight)
+    perm = None
+    scratch = None
+    if q_perm is not None and q_perm.device.type != "meta" and q_perm.numel() > 0:
+        assert q_perm.dtype == torch.int32 and q_perm.is_cuda
+        perm = q_perm
+        scratch = torch.empty_like(q_weight)
+    with torch.cuda.device(q_weight.device):
+        check(_lib.lib().vla_gptq_shuffle(q_weight.data_ptr(), _ptr(perm), _ptr(scratch),
+                                          q_weight.shape[0] * 32 // bit, q_weight.shape[1], bit,
+                                          _stream(q_weight.device)), "gptq_shuffle")
+
+
+def gptq_dequantize(b_q_weight, b_gptq_qzeros, b_gptq_scales, b_g_idx=None,
+                    shuffled: bool = False) -> torch.Tensor:
+    """The weight reconstruction half of the reference's gptq_gemm at M > 50
+    (csrc/quantization/gptq/q_gemm.cu:1496-1513), exposed for tests and for callers that
+    want the fp16 matrix."""
+    k, n = b_q_weight.shape[0] * 8, b_q_weight.shape[1]
+    out = torch.empty((k, n), dtype=torch.float16, device=b_q_weight.device)
+    gidx = b_g_idx if (b_g_idx is not None and b_g_idx.numel() > 0) else None
+    with torch.cuda.device(out.device):
+        check(_lib.lib().vla_gptq_dequantize(b_q_weight.data_ptr(), b_gptq_qzeros.data_ptr(),
+                                             b_gptq_scales.data_ptr(), _ptr(gidx),
+                                             out.data_ptr(), k, n, b_gptq_qzeros.shape[0],
+                                             1 if shuffled else 0, _stream(out.device)),
+              "gptq_dequantize")
+    return out
+
+
+def get_max_shared_memory_per_block_device_attribute(device: int = 0) -> int:
+    return _lib.lib().vla_get_max_shared_memory_per_block(device)
+
+
+def set_attention_path(mode: int) -> None:
+    """Test hook: 0 = pick the kernel per shape, 1 = force the generic kernel."""
+    check(_lib.lib().vla_set_attention_path(mode))

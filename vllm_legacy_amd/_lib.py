@@ -1,0 +1,83 @@
+"""ctypes binding of libvla_gfx950.so (the C-ABI declared in include/vla_paged_attention.h).
+
+There is no CPU fallback: if the library is missing, importing an op raises, and a non-zero
+status from the library becomes a RuntimeError carrying the message the reference would have
+raised through TORCH_CHECK.
+"""
+import ctypes as C
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libvla_gfx950.so")
+CSRC = os.path.join(HERE, "csrc")
+
+F16, BF16, F32 = 0, 1, 2
+KV_AUTO, KV_FP8_E4M3 = 0, 1
+PARTITION_SIZE = 512
+SWAP_D2D, SWAP_D2H, SWAP_H2D = 0, 1, 2
+
+_lib = None
+
+EXPORTS = [
+    "vla_status_string", "vla_last_hip_error", "vla_abi_version", "vla_set_attention_path",
+    "vla_kv_dtype_from_string", "vla_paged_attention_v1", "vla_paged_attention_v2",
+    "vla_reshape_and_cache", "vla_copy_blocks", "vla_swap_blocks", "vla_convert_fp8",
+    "vla_awq_dequantize", "vla_awq_gemm", "vla_gptq_dequantize", "vla_gptq_gemm",
+    "vla_gptq_shuffle", "vla_get_max_shared_memory_per_block",
+]
+
+
+def build(jobs: int = 8) -> str:
+    """Compile the HIP sources for gfx950 (hipcc cross-compiles without a GPU)."""
+    subprocess.check_call(["make", "-s", "-j%d" % jobs, "-C", CSRC])
+    return LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: build it with `make -C {CSRC}` (or "
+                "__graft_entry__.build()). This backend has no fallback path.")
+        # torch first: it brings its own HIP runtime, and the library must bind to the runtime
+        # that owns the device memory and streams it is handed (loading in the other order
+        # leaves launches failing with hipErrorNoDevice)
+        import torch  # noqa: F401
+        L = C.CDLL(LIB_PATH)
+        L.vla_status_string.restype = C.c_char_p
+        L.vla_status_string.argtypes = [C.c_int]
+        L.vla_kv_dtype_from_string.argtypes = [C.c_char_p]
+        i, i64, f, p = C.c_int, C.c_int64, C.c_float, C.c_void_p
+        L.vla_paged_attention_v1.argtypes = [p, p, p, p, i, i, i, i, i, f, p, p, i, i, p, i64,
+                                             i64, i64, i, i, f, i, i, i, i, i, p]
+        L.vla_paged_attention_v2.argtypes = [p, p, p, p, p, p, p, i, i, i, i, i, f, p, p, i, i,
+                                             p, i64, i64, i64, i, i, f, i, i, i, i, i, p]
+        L.vla_reshape_and_cache.argtypes = [p, p, p, p, p, i, i, i, i, i, i64, i64, i, i, f, p]
+        L.vla_copy_blocks.argtypes = [p, p, i, p, i, i64, p]
+        L.vla_swap_blocks.argtypes = [p, p, p, i, i64, i, p]
+        L.vla_convert_fp8.argtypes = [p, p, i64, i, i, f, i, p]
+        L.vla_awq_dequantize.argtypes = [p, p, p, p, i, i, i, p]
+        L.vla_awq_gemm.argtypes = [p, p, p, p, p, i, i, i, i, p]
+        L.vla_gptq_dequantize.argtypes = [p, p, p, p, p, i, i, i, i, p]
+        L.vla_gptq_gemm.argtypes = [p, p, p, p, p, p, i, i, i, i, i, i, p]
+        L.vla_gptq_shuffle.argtypes = [p, p, p, i, i, i, p]
+        L.vla_get_max_shared_memory_per_block.argtypes = [i]
+        _lib = L
+    return _lib
+
+
+def check(status: int, what: str = "") -> None:
+    if status != 0:
+        msg = lib().vla_status_string(status).decode()
+        if status == 7:
+            msg += f" (hipError_t {lib().vla_last_hip_error()})"
+        raise RuntimeError(f"{what}: {msg}" if what else msg)
+
+
+def kv_dtype_code(name: str) -> int:
+    code = lib().vla_kv_dtype_from_string(name.encode())
+    if code < 0:
+        raise RuntimeError(f"Unsupported data type of kv cache: {name}")
+    return code

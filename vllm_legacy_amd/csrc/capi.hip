@@ -1,0 +1,133 @@
+// extern "C" entry points of libvla_gfx950.so that are not defined next to their kernels:
+// status strings, argument validation and dispatch for the two attention ops.
+#include "vla_common.h"
+
+#include <string.h>
+
+namespace vla {
+static thread_local int g_last_hip_error = 0;
+void set_last_hip_error(int e) { g_last_hip_error = e; }
+static int g_attention_path = 0;  // 0 = pick per shape, 1 = always the generic kernel
+}  // namespace vla
+
+using namespace vla;
+
+extern "C" const char* vla_status_string(int status) {
+  switch (status) {
+    case VLA_OK: return "ok";
+    case VLA_ERR_HEAD_SIZE: return "Unsupported head size";
+    case VLA_ERR_BLOCK_SIZE: return "Unsupported block size";
+    case VLA_ERR_DTYPE: return "Unsupported input type of kv cache";
+    case VLA_ERR_KV_DTYPE: return "Unsupported data type of kv cache";
+    case VLA_ERR_ARG: return "Invalid argument";
+    case VLA_ERR_BLOCKSPARSE: return "Blocksparse paged attention is not supported by this backend";
+    case VLA_ERR_HIP: return "HIP runtime error";
+    case VLA_ERR_QUANT_SHAPE: return "Unsupported quantized weight shape";
+    default: return "unknown status";
+  }
+}
+
+extern "C" int vla_last_hip_error(void) { return g_last_hip_error; }
+extern "C" int vla_set_attention_path(int mode) {
+  if (mode != 0 && mode != 1) return VLA_ERR_ARG;
+  g_attention_path = mode;
+  return VLA_OK;
+}
+extern "C" int vla_abi_version(void) { return 1; }
+
+extern "C" int vla_kv_dtype_from_string(const char* name) {
+  if (!name) return -1;
+  if (!strcmp(name, "auto")) return VLA_KV_AUTO;
+  if (!strcmp(name, "fp8") || !strcmp(name, "fp8_e4m3")) return VLA_KV_FP8_E4M3;
+  return -1;
+}
+
+extern "C" int vla_get_max_shared_memory_per_block(int device) {
+  int v = 0;
+  if (hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, device) != hipSuccess)
+    return -1;
+  return v;
+}
+
+static int check_attn(const void* out, const void* query, const void* kc, const void* vc,
+                      int num_seqs, int num_heads, int num_kv_heads, int head_size,
+                      int block_size, const int* block_tables, const int* seq_lens,
+                      int max_blocks, int dtype, int kv_dtype, int vert_stride) {
+  if (!out || !query || !kc || !vc || !block_tables || !seq_lens) return VLA_ERR_ARG;
+  if (num_seqs < 0 || num_heads <= 0 || num_kv_heads <= 0 || num_heads % num_kv_heads ||
+      max_blocks <= 0)
+    return VLA_ERR_ARG;
+  if (dtype != VLA_F16 && dtype != VLA_BF16 && dtype != VLA_F32) return VLA_ERR_DTYPE;
+  if (kv_dtype != VLA_KV_AUTO && kv_dtype != VLA_KV_FP8_E4M3) return VLA_ERR_KV_DTYPE;
+  if (!block_size_supported(block_size)) return VLA_ERR_BLOCK_SIZE;
+  if (!head_size_supported(head_size)) return VLA_ERR_HEAD_SIZE;
+  // the reference switches to its block-sparse template when vert_stride > 1
+  // (attention_kernels.cu:821); that variant is outside this backend
+  if (vert_stride > 1) return VLA_ERR_BLOCKSPARSE;
+  return VLA_OK;
+}
+
+extern "C" int vla_paged_attention_v1(
+    void* out, const void* query, const void* key_cache, const void* value_cache, int num_seqs,
+    int num_heads, int num_kv_heads, int head_size, int block_size, float scale,
+    const int* block_tables, const int* seq_lens, int max_num_blocks_per_seq, int max_seq_len,
+    const float* alibi_slopes, int64_t q_stride, int64_t kv_block_stride, int64_t kv_head_stride,
+    int dtype, int kv_dtype, float kv_scale, int tp_rank, int blocksparse_local_blocks,
+    int blocksparse_vert_stride, int blocksparse_block_size, int blocksparse_head_sliding_step,
+    void* stream) {
+  (void)hipGetLastError();  // a stale error of some earlier HIP call must not fail this one
+  (void)max_seq_len; (void)tp_rank; (void)blocksparse_local_blocks;
+  (void)blocksparse_block_size; (void)blocksparse_head_sliding_step;
+  int rc = check_attn(out, query, key_cache, value_cache, num_seqs, num_heads, num_kv_heads,
+                      head_size, block_size, block_tables, seq_lens, max_num_blocks_per_seq,
+                      dtype, kv_dtype, blocksparse_vert_stride);
+  if (rc != VLA_OK) return rc;
+  if (num_seqs == 0) return VLA_OK;
+  AttnParams p{};
+  p.out = out; p.q = query; p.k_cache = key_cache; p.v_cache = value_cache;
+  p.block_tables = block_tables; p.seq_lens = seq_lens; p.alibi_slopes = alibi_slopes;
+  p.num_seqs = num_seqs; p.num_heads = num_heads; p.num_kv_heads = num_kv_heads;
+  p.head_size = head_size; p.block_size = block_size;
+  p.max_num_blocks_per_seq = max_num_blocks_per_seq; p.max_num_partitions = 0;
+  p.scale = scale; p.kv_scale = kv_scale;
+  p.q_stride = q_stride; p.kv_block_stride = kv_block_stride; p.kv_head_stride = kv_head_stride;
+  hipStream_t s = (hipStream_t)stream;
+  rc = g_attention_path == 1 ? -1 : launch_paged_attention_mfma(p, dtype, kv_dtype, s);
+  if (rc >= 0) return rc;
+  return launch_paged_attention_generic(p, dtype, kv_dtype, s);
+}
+
+extern "C" int vla_paged_attention_v2(
+    void* out, float* exp_sums, float* max_logits, void* tmp_out, const void* query,
+    const void* key_cache, const void* value_cache, int num_seqs, int num_heads,
+    int num_kv_heads, int head_size, int block_size, float scale, const int* block_tables,
+    const int* seq_lens, int max_num_blocks_per_seq, int max_seq_len, const float* alibi_slopes,
+    int64_t q_stride, int64_t kv_block_stride, int64_t kv_head_stride, int dtype, int kv_dtype,
+    float kv_scale, int tp_rank, int blocksparse_local_blocks, int blocksparse_vert_stride,
+    int blocksparse_block_size, int blocksparse_head_sliding_step, void* stream) {
+  (void)hipGetLastError();  // a stale error of some earlier HIP call must not fail this one
+  (void)tp_rank; (void)blocksparse_local_blocks;
+  (void)blocksparse_block_size; (void)blocksparse_head_sliding_step;
+  int rc = check_attn(out, query, key_cache, value_cache, num_seqs, num_heads, num_kv_heads,
+                      head_size, block_size, block_tables, seq_lens, max_num_blocks_per_seq,
+                      dtype, kv_dtype, blocksparse_vert_stride);
+  if (rc != VLA_OK) return rc;
+  if (!exp_sums || !max_logits || !tmp_out || max_seq_len <= 0) return VLA_ERR_ARG;
+  if (num_seqs == 0) return VLA_OK;
+  const int P = (max_seq_len + VLA_PARTITION_SIZE - 1) / VLA_PARTITION_SIZE;
+  AttnParams p{};
+  p.out = tmp_out; p.exp_sums = exp_sums; p.max_logits = max_logits;
+  p.q = query; p.k_cache = key_cache; p.v_cache = value_cache;
+  p.block_tables = block_tables; p.seq_lens = seq_lens; p.alibi_slopes = alibi_slopes;
+  p.num_seqs = num_seqs; p.num_heads = num_heads; p.num_kv_heads = num_kv_heads;
+  p.head_size = head_size; p.block_size = block_size;
+  p.max_num_blocks_per_seq = max_num_blocks_per_seq; p.max_num_partitions = P;
+  p.scale = scale; p.kv_scale = kv_scale;
+  p.q_stride = q_stride; p.kv_block_stride = kv_block_stride; p.kv_head_stride = kv_head_stride;
+  hipStream_t s = (hipStream_t)stream;
+  rc = g_attention_path == 1 ? -1 : launch_paged_attention_mfma(p, dtype, kv_dtype, s);
+  if (rc < 0) rc = launch_paged_attention_generic(p, dtype, kv_dtype, s);
+  if (rc != VLA_OK) return rc;
+  return launch_paged_attention_v2_reduce(out, exp_sums, max_logits, tmp_out, seq_lens, num_seqs,
+                                          num_heads, head_size, P, dtype, s);
+}

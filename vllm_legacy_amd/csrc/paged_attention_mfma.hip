@@ -1,0 +1,397 @@
+// Single-query paged attention for gfx950, 16-bit models (fp16 / bf16), KV cache in the model
+// dtype or fp8 e4m3.  This is the throughput kernel of the backend.
+//
+// Work split.  One 256-thread workgroup per (sequence, KV head[, 512-token partition]) serves
+// ALL query heads of that KV head (up to 16 per workgroup), so every K/V byte is fetched from
+// HBM once per KV head and not once per query head as in the reference's grid
+// (csrc/attention/attention_kernels.cu:734).  Each of the 4 waves walks its own share of the
+// token range in steps (64 tokens for fp8 KV, 32 for 16-bit KV) with a private online softmax;
+// the waves are merged through LDS at the end.
+//
+// Data path.  K and V go straight from HBM to registers with 16-byte loads per lane, one step
+// ahead of their use (K of step i+1 is in flight during the softmax / PV of step i, V of step i
+// during its QK); they are streamed once and shared by nothing, so staging them in LDS would
+// only add a round trip.  With several query heads per KV head both products are small dense
+// contractions, evaluated on the matrix cores as 16x16x32 tiles (rows = 16 tokens for q.K,
+// rows = up to 16 heads for P.V): that keeps the vector ALU for the fp8 -> fp16 conversions
+// and the softmax, which is what makes the kernel HBM-bound instead of issue-bound.  The only
+// LDS traffic in the loop is the 16 x step probability tile, which has to change lanes between
+// the two products.
+//
+//   q.K tile:  A = K   lane(g, r): token r of the 16-token block, 8 head dims
+//              B = q^T lane(g, c): head c, the same 8 head dims
+//              C       lane(g, c): head c, tokens 4g..4g+3
+//   P.V tile:  A = P   lane(g, r): head r, 8 tokens          (read from LDS)
+//              B = V   lane(g, c): head dim 16n + c, the same 8 tokens
+//              C       lane(g, c): head dim 16n + c, heads 4g..4g+3
+// The contraction index of an MFMA may be permuted freely as long as A and B agree, so each
+// lane's 16-byte load is used as it arrives: an fp8 K load (16 head dims of one token) feeds
+// two MFMAs, an fp8 V load (16 tokens of one head dim) likewise.
+//
+// Numerics: fp32 logits, fp32 running max / sum, probabilities rounded to the model dtype
+// before the value product (as the reference does, attention_kernels.cu:398-400), fp32
+// accumulation, normaliser 1 / (sum + 1e-6) (:342).  fp8 bytes convert exactly to fp16/bf16;
+// kv_scale is folded into the logit scale and the output instead of being multiplied into
+// every element (identical when kv_scale == 1).
+#include "vla_common.h"
+
+#include <math.h>
+
+namespace vla {
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kWaves = 4;
+constexpr int kBS = 16;  // KV block size handled here
+
+template <class S>
+__device__ __forceinline__ f32x4 mfma16(u32x4 a, u32x4 b, f32x4 c);
+template <>
+__device__ __forceinline__ f32x4 mfma16<F16>(u32x4 a, u32x4 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a),
+                                                __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+template <>
+__device__ __forceinline__ f32x4 mfma16<BF16>(u32x4 a, u32x4 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a),
+                                                 __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+template <class S>
+__device__ __forceinline__ uint32_t pack2(float a, float b) {
+  typename S::T x = S::from_f32(a), y = S::from_f32(b);
+  return (uint32_t)__builtin_bit_cast(uint16_t, x) |
+         ((uint32_t)__builtin_bit_cast(uint16_t, y) << 16);
+}
+
+// 8 fp8 bytes (two dwords) -> one MFMA operand of 8 16-bit floats
+template <class S>
+__device__ __forceinline__ u32x4 cvt8(uint32_t w0, uint32_t w1) {
+  u32x2 a = fp8x4_to_16<S>(w0), b = fp8x4_to_16<S>(w1);
+  u32x4 r;
+  r[0] = a[0]; r[1] = a[1]; r[2] = b[0]; r[3] = b[1];
+  return r;
+}
+
+// keep the first `nvalid` tokens of a 16-byte V load, zero the rest (they may hold NaNs,
+// attention_kernels.cu:420-430)
+template <bool FP8>
+__device__ __forceinline__ u32x4 mask_tokens(u32x4 v, int nvalid) {
+  constexpr int per_dword = FP8 ? 4 : 2;
+  constexpr int bits = FP8 ? 8 : 16;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    int nv = nvalid - w * per_dword;
+    nv = nv < 0 ? 0 : (nv > per_dword ? per_dword : nv);
+    uint32_t m = nv == per_dword ? 0xffffffffu : ((1u << (bits * nv)) - 1u);
+    v[w] &= m;
+  }
+  return v;
+}
+
+template <class S, bool FP8, int D, bool PARTITIONED>
+__global__ __launch_bounds__(kThreads, 2) void pa_mfma_kernel(AttnParams p, int heads_per_wg) {
+  using T = typename S::T;
+  constexpr int X = FP8 ? 16 : 8;          // elements per 16-byte K chunk
+  constexpr int TG = FP8 ? 16 : 8;         // tokens per 16-byte V load
+  constexpr int STEP = 4 * TG;             // tokens per wave step
+  constexpr int NT = STEP / 16;            // q.K tiles (16 tokens each) per step
+  constexpr int KL = D / (4 * X);          // K loads per tile per lane
+  constexpr int KS = D / 32;               // MFMA k-steps per q.K tile
+  constexpr int ND = D / 16;               // head-dim tiles of the output
+  constexpr int PM = FP8 ? 2 : 1;          // MFMAs fed by one V load
+  constexpr int CE = FP8 ? 1 : 2;          // cache element bytes
+  constexpr int P_PITCH = STEP * 2 + 16;   // bytes per head row of the probability tile
+  static_assert(KL * 4 * X == D && KS * 32 == D, "head size must be a multiple of 64 (fp8) / 32");
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int g = lane >> 4, c = lane & 15;
+
+  const int qpk = p.num_heads / p.num_kv_heads;
+  const int groups_per_kv = (qpk + heads_per_wg - 1) / heads_per_wg;
+  const int kv_head = blockIdx.x / groups_per_kv;
+  const int head_base = kv_head * qpk + (blockIdx.x % groups_per_kv) * heads_per_wg;
+  const int nheads = min(heads_per_wg, kv_head * qpk + qpk - head_base);
+  const int seq = blockIdx.y, part = blockIdx.z;
+
+  const int seq_len = p.seq_lens[seq];
+  const int tok_begin = PARTITIONED ? part * VLA_PARTITION_SIZE : 0;
+  if (tok_begin >= seq_len) return;
+  const int tok_end = PARTITIONED ? min(tok_begin + VLA_PARTITION_SIZE, seq_len) : seq_len;
+  const int last_blk = (tok_end - 1) / kBS;
+  const int* bt = p.block_tables + (int64_t)seq * p.max_num_blocks_per_seq;
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* p_lds = smem + wave * (16 * P_PITCH);  // this wave's probability tile
+
+  // ---- query fragments (B operand of q.K), zero rows for heads this workgroup does not own
+  u32x4 qf[KS];
+  {
+    const T* q = reinterpret_cast<const T*>(p.q) + (int64_t)seq * p.q_stride +
+                 (int64_t)(head_base + c) * D;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int d0 = FP8 ? 16 * (g + 4 * (ks >> 1)) + 8 * (ks & 1) : 8 * (g + 4 * ks);
+      qf[ks] = (c < nheads) ? *reinterpret_cast<const u32x4*>(q + d0) : u32x4{0, 0, 0, 0};
+    }
+  }
+  const float alibi = (p.alibi_slopes && c < nheads) ? p.alibi_slopes[head_base + c] : 0.f;
+  const float qk_scale = FP8 ? p.scale * p.kv_scale : p.scale;
+
+  const unsigned char* kbase = reinterpret_cast<const unsigned char*>(p.k_cache) +
+                               (int64_t)kv_head * p.kv_head_stride * CE;
+  const unsigned char* vbase = reinterpret_cast<const unsigned char*>(p.v_cache) +
+                               (int64_t)kv_head * p.kv_head_stride * CE;
+  const int64_t blk_bytes = p.kv_block_stride * CE;
+  // per-lane byte offsets inside a block
+  const int k_lane_off = (g * kBS + c) * 16;  // chunk g (+4j), token c
+  const int v_lane_off = FP8 ? c * kBS : (c * kBS + 8 * (g & 1)) * 2;
+
+  f32x4 o[ND];
+#pragma unroll
+  for (int n = 0; n < ND; ++n) o[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float m_run = -INFINITY, l_run = 0.f;
+
+  const int nsteps = (tok_end - tok_begin + STEP - 1) / STEP;
+
+  // block numbers of a step, clamped to the last block that holds live tokens
+  auto step_blocks = [&](int step, int (&blk)[NT]) {
+    const int b0 = (tok_begin + step * STEP) / kBS;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) blk[t] = bt[min(b0 + t, last_blk)];
+  };
+  auto load_k = [&](const int (&blk)[NT], u32x4 (&kb)[NT * KL]) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const unsigned char* kp = kbase + (int64_t)blk[t] * blk_bytes + k_lane_off;
+#pragma unroll
+      for (int j = 0; j < KL; ++j)
+        kb[t * KL + j] = *reinterpret_cast<const u32x4*>(kp + j * (4 * kBS * 16));
+    }
+  };
+
+  int cur_blk[NT];
+  u32x4 kb[NT * KL];
+  if (wave < nsteps) {
+    step_blocks(wave, cur_blk);
+    load_k(cur_blk, kb);
+  }
+
+  for (int step = wave; step < nsteps; step += kWaves) {
+    const int step_base = tok_begin + step * STEP;
+    const bool tail = step_base + STEP > tok_end;  // wave-uniform
+
+    // block numbers of this wave's next step (used after q.K)
+    int nxt_blk[NT] = {};
+    const bool has_next = step + kWaves < nsteps;
+    if (has_next) step_blocks(step + kWaves, nxt_blk);
+
+    // ---- V loads of this step (consumed after the softmax)
+    u32x4 vb[ND];
+    {
+      int vblk;
+      if constexpr (FP8) {
+        vblk = cur_blk[0];
+#pragma unroll
+        for (int t = 1; t < NT; ++t) vblk = (g == t) ? cur_blk[t] : vblk;
+      } else {
+        vblk = (g >> 1) ? cur_blk[1] : cur_blk[0];
+      }
+      const unsigned char* vp = vbase + (int64_t)vblk * blk_bytes + v_lane_off;
+#pragma unroll
+      for (int n = 0; n < ND; ++n)
+        vb[n] = *reinterpret_cast<const u32x4*>(vp + n * (16 * kBS * CE));
+    }
+
+    // ---- logits: NT tiles of 16 tokens x 16 heads
+    f32x4 s[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j < KL; ++j) {
+        const u32x4 kk = kb[t * KL + j];
+        if constexpr (FP8) {
+          acc = mfma16<S>(cvt8<S>(kk[0], kk[1]), qf[2 * j], acc);
+          acc = mfma16<S>(cvt8<S>(kk[2], kk[3]), qf[2 * j + 1], acc);
+        } else {
+          acc = mfma16<S>(kk, qf[j], acc);
+        }
+      }
+      s[t] = acc;
+    }
+
+    // ---- K loads of the next step go out now; they land during softmax + P.V
+    if (has_next) load_k(nxt_blk, kb);
+
+    // ---- online softmax for head c over this lane's tokens
+    float mx = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int tok = step_base + 16 * t + 4 * g + i;
+        float v = s[t][i] * qk_scale;
+        v += alibi * (float)(tok - seq_len + 1);
+        v = (tok < tok_end) ? v : -INFINITY;
+        s[t][i] = v;
+        mx = fmaxf(mx, v);
+      }
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = __expf(m_run - m_new);
+    float psum = 0.f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      float e[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        e[i] = __expf(s[t][i] - m_new);
+        psum += e[i];
+      }
+      u32x2 w;
+      w[0] = pack2<S>(e[0], e[1]);
+      w[1] = pack2<S>(e[2], e[3]);
+      *reinterpret_cast<u32x2*>(p_lds + c * P_PITCH + (16 * t + 4 * g) * 2) = w;
+    }
+    l_run = l_run * alpha + psum;
+
+    // rescale the output rows (heads 4g..4g+3 live in this lane) only when some max moved
+    if (__any(m_new > m_run)) {
+      float a[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a[i] = __shfl(alpha, 4 * g + i, 64);
+#pragma unroll
+      for (int n = 0; n < ND; ++n)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[n][i] *= a[i];
+    }
+    m_run = m_new;
+
+    // ---- probability fragments (A operand of P.V): head c, this lane's 8 tokens per MFMA
+    __builtin_amdgcn_wave_barrier();
+    u32x4 pf[PM];
+#pragma unroll
+    for (int mm = 0; mm < PM; ++mm)
+      pf[mm] = *reinterpret_cast<const u32x4*>(p_lds + c * P_PITCH + (TG * g + 8 * mm) * 2);
+    __builtin_amdgcn_wave_barrier();
+
+    // ---- P.V
+    const int nvalid = tok_end - (step_base + TG * g);  // live tokens in this lane's V loads
+#pragma unroll
+    for (int n = 0; n < ND; ++n) {
+      u32x4 vv = vb[n];
+      if (tail) vv = mask_tokens<FP8>(vv, nvalid);
+      if constexpr (FP8) {
+        o[n] = mfma16<S>(pf[0], cvt8<S>(vv[0], vv[1]), o[n]);
+        o[n] = mfma16<S>(pf[1], cvt8<S>(vv[2], vv[3]), o[n]);
+      } else {
+        o[n] = mfma16<S>(pf[0], vv, o[n]);
+      }
+    }
+
+#pragma unroll
+    for (int t = 0; t < NT; ++t) cur_blk[t] = nxt_blk[t];
+  }
+
+  // ---- merge the waves
+  l_run += __shfl_xor(l_run, 16, 64);
+  l_run += __shfl_xor(l_run, 32, 64);
+  __syncthreads();  // every wave is done with its probability tile
+  float* ml = reinterpret_cast<float*>(smem);            // [kWaves][2][16]  max, sum
+  float* ol = ml + kWaves * 32;                          // [kWaves][heads_per_wg][D]
+  if (g == 0) {
+    ml[wave * 32 + c] = m_run;
+    ml[wave * 32 + 16 + c] = l_run;
+  }
+#pragma unroll
+  for (int n = 0; n < ND; ++n)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int h = 4 * g + i;
+      if (h < nheads) ol[(wave * heads_per_wg + h) * D + 16 * n + c] = o[n][i];
+    }
+  __syncthreads();
+
+  const float out_scale = FP8 ? p.kv_scale : 1.f;
+  T* out = reinterpret_cast<T*>(p.out);
+  for (int idx = threadIdx.x; idx < nheads * D; idx += kThreads) {
+    const int h = idx / D, d = idx - h * D;
+    float M = ml[h];
+#pragma unroll
+    for (int w = 1; w < kWaves; ++w) M = fmaxf(M, ml[w * 32 + h]);
+    float L = 0.f, O = 0.f;
+#pragma unroll
+    for (int w = 0; w < kWaves; ++w) {
+      const float f = __expf(ml[w * 32 + h] - M);
+      L += ml[w * 32 + 16 + h] * f;
+      O += ol[(w * heads_per_wg + h) * D + d] * f;
+    }
+    const float r = O * out_scale / (L + 1e-6f);
+    const int64_t sh = (int64_t)seq * p.num_heads + head_base + h;
+    if (PARTITIONED) {
+      out[(sh * p.max_num_partitions + part) * D + d] = S::from_f32(r);
+      if (d == 0) {
+        p.exp_sums[sh * p.max_num_partitions + part] = L;
+        p.max_logits[sh * p.max_num_partitions + part] = M;
+      }
+    } else {
+      out[sh * D + d] = S::from_f32(r);
+    }
+  }
+}
+
+template <class S, bool FP8, int D>
+int launch_t(const AttnParams& p, hipStream_t s) {
+  const int qpk = p.num_heads / p.num_kv_heads;
+  // query heads per workgroup: the whole GQA group when it fits the 16 rows of a tile
+  int hpw = qpk <= 16 ? qpk : 16;
+  const int groups_per_kv = (qpk + hpw - 1) / hpw;
+  constexpr int STEP = FP8 ? 64 : 32;
+  const size_t p_bytes = (size_t)kWaves * 16 * (STEP * 2 + 16);
+  const size_t merge_bytes = (size_t)kWaves * 32 * 4 + (size_t)kWaves * hpw * D * 4;
+  const size_t smem = p_bytes > merge_bytes ? p_bytes : merge_bytes;
+  if (smem > 64 * 1024) return -1;  // beyond the default dynamic-LDS limit: generic kernel
+  dim3 grid(p.num_kv_heads * groups_per_kv, p.num_seqs,
+            p.max_num_partitions > 0 ? p.max_num_partitions : 1);
+  if (p.max_num_partitions > 0)
+    hipLaunchKernelGGL((pa_mfma_kernel<S, FP8, D, true>), grid, dim3(kThreads), smem, s, p, hpw);
+  else
+    hipLaunchKernelGGL((pa_mfma_kernel<S, FP8, D, false>), grid, dim3(kThreads), smem, s, p, hpw);
+  VLA_HIP_CHECK(hipGetLastError());
+  return VLA_OK;
+}
+
+template <class S, bool FP8>
+int launch_d(const AttnParams& p, hipStream_t s) {
+  switch (p.head_size) {
+    case 64: return launch_t<S, FP8, 64>(p, s);
+    case 128: return launch_t<S, FP8, 128>(p, s);
+    case 192: return launch_t<S, FP8, 192>(p, s);
+    case 256: return launch_t<S, FP8, 256>(p, s);
+    case 96:
+      if constexpr (!FP8) return launch_t<S, false, 96>(p, s);
+      return -1;
+    default: return -1;
+  }
+}
+
+}  // namespace
+
+int launch_paged_attention_mfma(const AttnParams& p, int dtype, int kv_dtype, hipStream_t s) {
+  if (p.block_size != kBS) return -1;
+  if (dtype != VLA_F16 && dtype != VLA_BF16) return -1;
+  const bool fp8 = kv_dtype == VLA_KV_FP8_E4M3;
+  const int ce = fp8 ? 1 : 2;
+  // 16-byte loads: aligned bases and strides, 16-byte aligned query rows
+  if (((uintptr_t)p.k_cache | (uintptr_t)p.v_cache | (uintptr_t)p.q) % 16) return -1;
+  if ((p.kv_block_stride * ce) % 16 || (p.kv_head_stride * ce) % 16 || (p.q_stride * 2) % 16)
+    return -1;
+  if (dtype == VLA_F16) return fp8 ? launch_d<F16, true>(p, s) : launch_d<F16, false>(p, s);
+  return fp8 ? launch_d<BF16, true>(p, s) : launch_d<BF16, false>(p, s);
+}
+
+}  // namespace vla

@@ -1,0 +1,90 @@
+"""Collectives of the tensor-parallel decode path.
+
+Mirrors vllm/distributed/communication_op.py:73-100 (all-reduce), :103-127 (all-gather),
+:130-160 (gather), :227-317 (broadcast_tensor_dict).  On ROCm the reference ends up in
+torch.distributed / RCCL for every one of these (its custom all-reduce is CUDA-only,
+device_communicators/custom_all_reduce.py:28-31); so does this module.  The message of the hot
+all-reduce is the [tokens, hidden] partial output of a row-parallel linear (2 MiB for
+Llama-3-8B at 256 tokens), issued in place on the compute stream.
+"""
+from typing import Any, Dict, Optional
+
+import torch
+import torch.distributed as dist
+
+from .parallel_state import (get_tensor_model_parallel_cpu_group,
+                             get_tensor_model_parallel_group,
+                             get_tensor_model_parallel_rank,
+                             get_tensor_model_parallel_src_rank,
+                             get_tensor_model_parallel_world_size)
+
+
+def tensor_model_parallel_all_reduce(input_: torch.Tensor) -> torch.Tensor:
+    """SUM over the TP group, in place; returns its argument."""
+    if get_tensor_model_parallel_world_size() == 1:
+        return input_
+    dist.all_reduce(input_, group=get_tensor_model_parallel_group())
+    return input_
+
+
+def tensor_model_parallel_all_gather(input_: torch.Tensor, dim: int = -1) -> torch.Tensor:
+    world = get_tensor_model_parallel_world_size()
+    if world == 1:
+        return input_
+    if dim < 0:
+        dim += input_.dim()
+    size = input_.size()
+    out = torch.empty((world, ) + size, dtype=input_.dtype, device=input_.device)
+    dist.all_gather_into_tensor(out, input_.contiguous(), group=get_tensor_model_parallel_group())
+    out = out.movedim(0, dim)
+    return out.reshape(size[:dim] + (world * size[dim], ) + size[dim + 1:])
+
+
+def tensor_model_parallel_gather(input_: torch.Tensor, dst: int = 0, dim: int = -1) -> Optional[torch.Tensor]:
+    """Concatenate along `dim` on rank `dst` of the group; None elsewhere (logits gather,
+    vllm/model_executor/layers/logits_processor.py:68)."""
+    world = get_tensor_model_parallel_world_size()
+    if world == 1:
+        return input_
+    if dim < 0:
+        dim += input_.dim()
+    me = get_tensor_model_parallel_rank()
+    bufs = [torch.empty_like(input_) for _ in range(world)] if me == dst else None
+    dist.gather(input_.contiguous(), bufs, dst=get_tensor_model_parallel_src_rank() + dst,
+                group=get_tensor_model_parallel_group())
+    return torch.cat(bufs, dim=dim) if me == dst else None
+
+
+def broadcast_tensor_dict(tensor_dict: Optional[Dict[str, Any]] = None, src: int = 0) -> Dict[str, Any]:
+    """Driver -> workers broadcast of the per-step metadata (block tables, slot mapping,
+    sequence lengths): python values and tensor shapes travel over Gloo, tensor payloads over
+    the device group."""
+    world = get_tensor_model_parallel_world_size()
+    if world == 1:
+        return tensor_dict or {}
+    group, cpu_group = get_tensor_model_parallel_group(), get_tensor_model_parallel_cpu_group()
+    src_global = get_tensor_model_parallel_src_rank() + src
+    me = get_tensor_model_parallel_rank()
+    if me == src:
+        assert isinstance(tensor_dict, dict)
+        meta = [(k, ("t", v.dtype, tuple(v.shape), v.device.type)) if isinstance(v, torch.Tensor)
+                else (k, ("v", v)) for k, v in tensor_dict.items()]
+        dist.broadcast_object_list([meta], src=src_global, group=cpu_group)
+        for k, v in tensor_dict.items():
+            if isinstance(v, torch.Tensor) and v.numel():
+                dist.broadcast(v, src=src_global, group=group if v.is_cuda else cpu_group)
+        return tensor_dict
+    box = [None]
+    dist.broadcast_object_list(box, src=src_global, group=cpu_group)
+    out: Dict[str, Any] = {}
+    for k, spec in box[0]:
+        if spec[0] == "v":
+            out[k] = spec[1]
+            continue
+        _, dtype, shape, devtype = spec
+        dev = torch.device("cuda", torch.cuda.current_device()) if devtype == "cuda" else "cpu"
+        t = torch.empty(shape, dtype=dtype, device=dev)
+        if t.numel():
+            dist.broadcast(t, src=src_global, group=group if t.is_cuda else cpu_group)
+        out[k] = t
+    return out

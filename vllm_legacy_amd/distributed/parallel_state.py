@@ -1,0 +1,98 @@
+"""Tensor-parallel process groups for the decode path: one process per GPU, RCCL over xGMI.
+
+Mirrors the part of vllm/distributed/parallel_state.py the hot path uses
+(init_distributed_environment :80-125, initialize_model_parallel :128-203, the accessors) with
+one device group (backend "nccl" = RCCL on ROCm, "gloo" on CPU for tests) and one Gloo group
+for host-side metadata.  Pipeline parallelism is rejected by the reference's own config
+(vllm/config.py:606-608) and has no counterpart here.
+"""
+import os
+from typing import Optional
+
+import torch
+import torch.distributed as dist
+
+_TP_GROUP: Optional[dist.ProcessGroup] = None
+_TP_CPU_GROUP: Optional[dist.ProcessGroup] = None
+_TP_RANKS = None
+
+
+def init_distributed_environment(world_size: int = -1, rank: int = -1,
+                                 distributed_init_method: str = "env://", local_rank: int = -1,
+                                 backend: str = "nccl") -> None:
+    """World group + a warm-up all-reduce (the reference does one to surface broken links
+    early, parallel_state.py:107-125)."""
+    if not dist.is_initialized():
+        kw = {}
+        if world_size >= 0:
+            kw.update(world_size=world_size, rank=rank)
+        dist.init_process_group(backend=backend, init_method=distributed_init_method, **kw)
+    if backend == "nccl":
+        if local_rank < 0:
+            local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        torch.cuda.set_device(local_rank)
+        t = torch.ones(1, device=f"cuda:{local_rank}")
+        dist.all_reduce(t)
+        torch.cuda.synchronize()
+        assert int(t.item()) == dist.get_world_size()
+
+
+def initialize_model_parallel(tensor_model_parallel_size: int = 1, backend: Optional[str] = None) -> None:
+    """Consecutive ranks form a TP group: [0..tp-1], [tp..2tp-1], ... (parallel_state.py:150-166)."""
+    global _TP_GROUP, _TP_CPU_GROUP, _TP_RANKS
+    assert dist.is_initialized()
+    world = dist.get_world_size()
+    assert world % tensor_model_parallel_size == 0
+    backend = backend or dist.get_backend()
+    me = dist.get_rank()
+    for i in range(world // tensor_model_parallel_size):
+        ranks = list(range(i * tensor_model_parallel_size, (i + 1) * tensor_model_parallel_size))
+        grp = dist.new_group(ranks, backend=backend)
+        cpu_grp = dist.new_group(ranks, backend="gloo")
+        if me in ranks:
+            _TP_GROUP, _TP_CPU_GROUP, _TP_RANKS = grp, cpu_grp, ranks
+
+
+def model_parallel_is_initialized() -> bool:
+    return _TP_GROUP is not None
+
+
+def ensure_model_parallel_initialized(tensor_model_parallel_size: int, backend: Optional[str] = None) -> None:
+    if not model_parallel_is_initialized():
+        initialize_model_parallel(tensor_model_parallel_size, backend)
+        return
+    assert get_tensor_model_parallel_world_size() == tensor_model_parallel_size
+
+
+def get_tensor_model_parallel_group():
+    assert _TP_GROUP is not None, "tensor model parallel group is not initialized"
+    return _TP_GROUP
+
+
+def get_tensor_model_parallel_cpu_group():
+    assert _TP_CPU_GROUP is not None
+    return _TP_CPU_GROUP
+
+
+def get_tensor_model_parallel_world_size() -> int:
+    if _TP_GROUP is None:
+        return 1
+    return dist.get_world_size(group=_TP_GROUP)
+
+
+def get_tensor_model_parallel_rank() -> int:
+    if _TP_GROUP is None:
+        return 0
+    return dist.get_rank(group=_TP_GROUP)
+
+
+def get_tensor_model_parallel_src_rank() -> int:
+    return _TP_RANKS[0] if _TP_RANKS else 0
+
+
+def destroy_model_parallel() -> None:
+    global _TP_GROUP, _TP_CPU_GROUP, _TP_RANKS
+    for g in (_TP_GROUP, _TP_CPU_GROUP):
+        if g is not None:
+            dist.destroy_process_group(g)
+    _TP_GROUP = _TP_CPU_GROUP = _TP_RANKS = None
