@@ -1,0 +1,311 @@
+#!/usr/bin/env python3
+"""Decode-step benchmark of the gfx950 quantized paged-attention backend.
+
+    python bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[2], the configuration the metric is quoted on): one decode step
+of Llama-3-8B with AWQ int4 weights and an fp8 KV cache at batch 256, context 4096 -- 32 layers
+of {int4 qkv GEMM, rotary, KV-cache write, paged attention over 4096 cached tokens, int4 o_proj,
+int4 MLP}, lm_head and greedy sampling -- on synthetic random weights and caches.  With N > 1
+(launched by torch.distributed.run) the model is tensor-parallel over N GPUs with RCCL
+all-reduces, the same batch: strong scaling.
+
+One JSON line is printed by rank 0.  `value` is batch / step time with everything resident in
+HBM.  `roofline` describes the dominant kernel (paged attention): algorithmic bytes per launch /
+its launch duration measured with HIP events on the launch stream.  `cpu_baseline` times the
+reference's own CPU attention kernel (oracle/_ref, built from the reference's csrc/cpu) -- or the
+oracle port if the host lacks AVX-512 -- on a bounded sample; it is a baseline only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--seq", type=int, default=4096)
+    ap.add_argument("--layers", type=int, default=32)
+    ap.add_argument("--quant", default="awq", choices=["awq", "gptq", "none"])
+    ap.add_argument("--kv", default="fp8", choices=["fp8", "auto"])
+    ap.add_argument("--model", default="llama3-8b", choices=["llama3-8b", "llama3-70b", "tiny"])
+    ap.add_argument("--no-graph", action="store_true", help="run the step eagerly")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--attn-only", action="store_true",
+                    help="time only the paged-attention launches (kernel study)")
+    return ap.parse_args()
+
+
+def fill_kv_caches(model, num_blocks, block_size, kv, device):
+    """Layer 0 gets U(-scale, scale) values (quantised with convert_fp8 for an fp8 cache, the
+    reference's recipe, vllm/utils.py:324-341, :398-446); the other layers are block-rolled
+    copies of it, which keeps start-up short without making any layer's data cache-resident."""
+    from vllm_legacy_amd import _custom_ops as ops
+    shape = model.kv_cache_shape(num_blocks, block_size)
+    dtype = torch.uint8 if kv == "fp8" else model.dtype
+    scale = model.cfg.head_dim**-0.5
+    g = torch.Generator(device=device).manual_seed(1234)
+    first = torch.empty(shape, dtype=dtype, device=device)
+    flat = first.view(-1)
+    chunk = 1 << 28
+    for i in range(0, flat.numel(), chunk):
+        n = min(chunk, flat.numel() - i)
+        tmp = torch.empty(n, dtype=torch.float16, device=device).uniform_(-scale, scale, generator=g)
+        if kv == "fp8":
+            ops.convert_fp8(flat[i:i + n], tmp)
+        else:
+            flat[i:i + n] = tmp.to(dtype)
+    caches = [first]
+    for layer in range(1, len(model.layers)):
+        # block-rolled copy built from contiguous slice copies (torch.roll's gather kernel
+        # faults on tensors of more than 2^31 elements)
+        c = torch.empty_like(first)
+        s = (17 * layer) % num_blocks
+        for half in range(2):
+            c[half, s:].copy_(first[half, :num_blocks - s])
+            c[half, :s].copy_(first[half, num_blocks - s:])
+        caches.append(c)
+    return caches
+
+
+def cpu_baseline(args):
+    """Reference CPU paged_attention_v1 (bf16, block 16: it has no fp8 and no int4 path,
+    csrc/cpu/attention.cpp:241, :429) on a bounded sample of the same attention shape."""
+    import numpy as np
+    from oracle import build_ref
+    from oracle import oracle as O
+    hq, hkv, d, bs, S = 32, 8, 128, 16, args.seq
+    b = 4
+    nb = b * S // bs
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    threads = int(os.environ.get("OMP_NUM_THREADS", cores))
+    scale = d**-0.5
+    g = torch.Generator().manual_seed(0)
+    q = (torch.rand(b, hq, d, generator=g) * 2 - 1).mul(scale).bfloat16()
+    kc = (torch.rand(nb, hkv, d // 8, bs, 8, generator=g) * 2 - 1).mul(scale).bfloat16()
+    vc = (torch.rand(nb, hkv, d, bs, generator=g) * 2 - 1).mul(scale).bfloat16()
+    bt = torch.randperm(nb, generator=g).to(torch.int32).view(b, S // bs)
+    sl = torch.full((b, ), S, dtype=torch.int32)
+    ref = build_ref.load_ref() if build_ref.ref_usable() else None
+    if ref is not None:
+        kind = "reference"
+        out = torch.empty_like(q)
+
+        def run():
+            ref.paged_attention_v1(out, q, kc, vc, hkv, scale, bt, sl, bs, S, None, "auto", 1.0, 0,
+                                   0, 0, 64, 0)
+    else:
+        kind = "port"
+        from tests import pa_testlib as T
+        qb, kb, vb = T.bits(q), T.bits(kc), T.bits(vc)
+        btn, sln = bt.numpy(), sl.numpy()
+
+        def run():
+            O.paged_attention_v1(qb, kb, vb, btn, sln, scale, O.DT_BF16)
+    run()
+    t0 = time.perf_counter()
+    iters = 0
+    while time.perf_counter() - t0 < 10.0:
+        run()
+        iters += 1
+    dt = (time.perf_counter() - t0) / iters
+    layer_calls_per_step = args.layers
+    tok_s = b / (dt * layer_calls_per_step)
+    gbs = 2 * hkv * d * S * b * 2 / dt / 1e9
+    return {
+        "value": round(tok_s, 3), "unit": "tokens/s", "cores": threads, "kind": kind,
+        "sample": (f"attention only: csrc/cpu paged_attention_v1, bf16 KV (the CPU path has no fp8/int4), "
+                   f"{b} sequences x {S} tokens, Hq=32 Hkv=8 D=128 block 16, {iters} timed calls, "
+                   f"{dt * 1e3:.1f} ms per layer call = {gbs:.1f} GB/s; tokens/s = {b} / (32 layer calls)"),
+    }
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        from vllm_legacy_amd.distributed import parallel_state as ps
+        ps.init_distributed_environment(local_rank=local_rank, backend="nccl")
+        ps.initialize_model_parallel(world)
+    assert world == args.gpus or world == 1, "launch with torch.distributed.run for --gpus > 1"
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+
+    from vllm_legacy_amd import _custom_ops as ops
+    from vllm_legacy_amd.attention.backends.gfx950_paged import Gfx950PagedAttentionMetadata
+    from vllm_legacy_amd.model.llama_decode import LlamaConfig, LlamaDecodeModel
+
+    cfg = {"llama3-8b": LlamaConfig.llama3_8b, "llama3-70b": LlamaConfig.llama3_70b,
+           "tiny": LlamaConfig.tiny}[args.model]()
+    cfg.num_hidden_layers = args.layers
+    B, S, BS = args.batch, args.seq, 16
+    torch.manual_seed(0)
+    model = LlamaDecodeModel(cfg, quant=args.quant, kv_cache_dtype=args.kv, device=device)
+    num_blocks = B * (S // BS) + 8
+    kv_caches = fill_kv_caches(model, num_blocks, BS, args.kv, device)
+
+    g = torch.Generator(device=device).manual_seed(7)
+    block_tables = torch.randperm(num_blocks, generator=g, device=device)[:B * (S // BS)]
+    block_tables = block_tables.to(torch.int32).view(B, S // BS).contiguous()
+    seq_lens = torch.full((B, ), S, dtype=torch.int32, device=device)
+    positions = torch.full((B, ), S - 1, dtype=torch.int64, device=device)
+    slot_mapping = block_tables[:, (S - 1) // BS].to(torch.int64) * BS + (S - 1) % BS
+    input_ids = torch.randint(0, cfg.vocab_size, (B, ), generator=g, device=device)
+    meta = Gfx950PagedAttentionMetadata(
+        num_prefills=0, num_prefill_tokens=0, num_decode_tokens=B, slot_mapping=slot_mapping,
+        seq_lens=None, seq_lens_tensor=seq_lens, max_query_len=None, max_prefill_seq_len=0,
+        max_decode_seq_len=S, query_start_loc=None, seq_start_loc=None, use_cuda_graph=True,
+        context_lens_tensor=None, block_tables=block_tables)
+    next_ids = torch.empty((B, ), dtype=torch.int64, device=device)
+
+    @torch.inference_mode()
+    def step():
+        hidden = model(input_ids, positions, kv_caches, meta)
+        logits = model.compute_logits(hidden)
+        if logits is not None:
+            next_ids.copy_(torch.argmax(logits, dim=-1))
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+
+    # ---- optional graph capture (decode is replayed from a graph in the reference too,
+    # vllm/worker/model_runner.py:512-515)
+    use_graph = not args.no_graph
+    graph = None
+    stream = torch.cuda.Stream(device=device)
+    with torch.cuda.stream(stream):
+        step()  # first call: lazy inits (e.g. the GPTQ shuffle)
+        torch.cuda.synchronize()
+        if use_graph:
+            try:
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph, stream=stream):
+                    step()
+            except Exception as e:  # e.g. a collective that cannot be captured
+                if rank == 0:
+                    print(f"[bench] graph capture failed ({type(e).__name__}: {e}); running eagerly",
+                          file=sys.stderr)
+                graph = None
+                torch.cuda.synchronize()
+        run = graph.replay if graph is not None else step
+
+        for _ in range(args.warmup):
+            run()
+        torch.cuda.synchronize()
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            run()
+        torch.cuda.synchronize()
+        barrier()
+        elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = elapsed / args.steps * 1e3
+
+    # ---- dominant kernel: paged attention, timed per launch with HIP events on its stream
+    layer0 = model.layers[0]
+    hq, hkv, d = layer0.hq, layer0.hkv, cfg.head_dim
+    e_kv = 1 if args.kv == "fp8" else 2
+    algo_bytes = (2 * hkv * d * S * B * e_kv          # every K and V byte once per KV head
+                  + 4 * B * (S // BS)                  # block tables
+                  + 2 * B * hq * d * 2 + 8 * B)        # q in, out, seq_lens
+    q = torch.empty((B, hq, d), dtype=model.dtype, device=device).uniform_(-d**-0.5, d**-0.5)
+    out = torch.empty_like(q)
+    from vllm_legacy_amd.attention.ops.paged_attn import PagedAttention
+    caches = [PagedAttention.split_kv_cache(c, hkv, d) for c in kv_caches]
+    kvd = "fp8" if args.kv == "fp8" else "auto"
+    with torch.cuda.stream(stream):
+        def attn(layer):
+            kc, vc = caches[layer]
+            ops.paged_attention_v1(out, q, kc, vc, hkv, d**-0.5, block_tables, seq_lens, BS, S,
+                                   None, kvd, 1.0)
+        for layer in range(len(caches)):
+            attn(layer)
+        torch.cuda.synchronize()
+        reps = max(1, min(args.steps, 5))
+        evs = []
+        for _ in range(reps):
+            for layer in range(len(caches)):
+                a, b_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record(stream)
+                attn(layer)
+                b_.record(stream)
+                evs.append((a, b_))
+        torch.cuda.synchronize()
+        attn_ms = sum(a.elapsed_time(b_) for a, b_ in evs) / len(evs)
+    achieved = algo_bytes / (attn_ms * 1e-3) / 1e9
+
+    if rank == 0:
+        result = {
+            "metric": "decode tokens/s, Llama-3-8B AWQ-int4 fp8-KV, bs=256 seq=4k (+ achieved HBM GB/s of paged attention in `roofline`)",
+            "value": round(B / (ms_per_step * 1e-3), 2),
+            "unit": "tokens/s",
+            "n_gpus": args.gpus,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f16",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{args.model} decode step, {args.quant} int4 weights, {args.kv} KV cache, "
+                            f"batch {B}, context {S}, block 16, {args.layers} layers",
+                "parallelism": f"tp{world}",
+                "graph": graph is not None,
+                "global_batch": B,
+                "seq_len": S,
+            },
+            "roofline": {
+                "kernel": "paged_attention_v1 (pa_mfma_kernel)",
+                "bound": "hbm",
+                "achieved": round(achieved, 1),
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4),
+                "traffic": None,
+                "algorithmic_bytes_per_launch": algo_bytes,
+                "launch_ms": round(attn_ms, 4),
+                "attention_share_of_step": round(attn_ms * len(caches) / ms_per_step, 3),
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                result["cpu_baseline"] = cpu_baseline(args)
+            except Exception as e:
+                result["cpu_baseline"] = {"value": None, "unit": "tokens/s", "cores": 0,
+                                          "kind": "port", "sample": f"failed: {e}"}
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

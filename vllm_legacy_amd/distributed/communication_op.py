@@ -34,9 +34,11 @@ def tensor_model_parallel_all_gather(input_: torch.Tensor, dim: int = -1) -> tor
     if dim < 0:
         dim += input_.dim()
     size = input_.size()
-    out = torch.empty((world, ) + size, dtype=input_.dtype, device=input_.device)
+    # flat [world * size0, ...] output: the layout every backend's all_gather_into_tensor accepts
+    out = torch.empty((world * size[0], ) + tuple(size[1:]), dtype=input_.dtype,
+                      device=input_.device)
     dist.all_gather_into_tensor(out, input_.contiguous(), group=get_tensor_model_parallel_group())
-    out = out.movedim(0, dim)
+    out = out.view((world, ) + tuple(size)).movedim(0, dim)
     return out.reshape(size[:dim] + (world * size[dim], ) + size[dim + 1:])
 
 

@@ -1,0 +1,218 @@
+"""Synthetic-weight Llama decode stack: the caller side of the hot path.
+
+Shapes and layer order follow the reference's vllm/model_executor/models/llama.py:86-264
+(qkv_proj -> rotary -> attention -> o_proj, gate_up_proj -> SiluAndMul -> down_proj, Megatron
+column/row sharding with an all-reduce after each row-parallel linear,
+vllm/model_executor/layers/linear.py:755-779).  The int4 linears and the attention (cache write +
+paged attention) run on the gfx950 library; RMSNorm, rotary embedding, SwiGLU, the embedding
+lookup and the fp16 lm_head are plain PyTorch-ROCm ops (they are outside this backend's scope and
+stand in for the reference's own kernels).
+
+Weights are random (no checkpoints are available offline); this module exists to drive the
+decode-step benchmark and the tensor-parallel tests, not to load models.
+"""
+from dataclasses import dataclass
+from typing import List, Optional
+
+import torch
+import torch.nn as nn
+
+from vllm_legacy_amd.attention.layer import Attention
+from vllm_legacy_amd.distributed.communication_op import (tensor_model_parallel_all_reduce,
+                                                          tensor_model_parallel_gather)
+from vllm_legacy_amd.distributed.parallel_state import (get_tensor_model_parallel_rank,
+                                                        get_tensor_model_parallel_world_size)
+from vllm_legacy_amd.quantization.awq import AWQConfig, AWQLinearMethod
+from vllm_legacy_amd.quantization.gptq import GPTQConfig, GPTQLinearMethod
+
+
+@dataclass
+class LlamaConfig:
+    hidden_size: int = 4096
+    intermediate_size: int = 14336
+    num_hidden_layers: int = 32
+    num_attention_heads: int = 32
+    num_key_value_heads: int = 8
+    head_dim: int = 128
+    vocab_size: int = 128256
+    rms_norm_eps: float = 1e-5
+    rope_theta: float = 500000.0
+    max_position_embeddings: int = 8192
+
+    @staticmethod
+    def llama3_8b() -> "LlamaConfig":
+        return LlamaConfig()
+
+    @staticmethod
+    def llama3_70b() -> "LlamaConfig":
+        return LlamaConfig(hidden_size=8192, intermediate_size=28672, num_hidden_layers=80,
+                           num_attention_heads=64, num_key_value_heads=8)
+
+    @staticmethod
+    def tiny() -> "LlamaConfig":
+        return LlamaConfig(hidden_size=256, intermediate_size=512, num_hidden_layers=2,
+                           num_attention_heads=8, num_key_value_heads=2, head_dim=32 * 2,
+                           vocab_size=1024, max_position_embeddings=512)
+
+
+def rms_norm(x: torch.Tensor, weight: torch.Tensor, eps: float) -> torch.Tensor:
+    v = x.float()
+    v = v * torch.rsqrt(v.pow(2).mean(-1, keepdim=True) + eps)
+    return v.to(x.dtype) * weight
+
+
+def apply_rotary_neox(positions: torch.Tensor, q: torch.Tensor, k: torch.Tensor,
+                      cos_sin_cache: torch.Tensor) -> None:
+    """In-place NeoX-style rotation of q [T, Hq, D] and k [T, Hkv, D]
+    (csrc/pos_encoding_kernels.cu:71-93 semantics)."""
+    cs = cos_sin_cache[positions]                    # [T, D]
+    half = cs.shape[-1] // 2
+    cos, sin = cs[:, None, :half], cs[:, None, half:]
+    for t in (q, k):
+        x1, x2 = t[..., :half].clone(), t[..., half:].clone()
+        t[..., :half] = (x1 * cos - x2 * sin).to(t.dtype)
+        t[..., half:] = (x2 * cos + x1 * sin).to(t.dtype)
+
+
+class QuantLinear(nn.Module):
+    """Column- or row-parallel int4 linear with random weights in the checkpoint layout."""
+
+    def __init__(self, in_features: int, out_features: int, quant: str, group_size: int, device,
+                 generator: torch.Generator, dtype=torch.float16):
+        super().__init__()
+        self.quant = quant
+        if quant == "awq":
+            self.method = AWQLinearMethod(AWQConfig(4, group_size))
+        elif quant == "gptq":
+            self.method = GPTQLinearMethod(GPTQConfig(4, group_size, False))
+        elif quant == "none":
+            self.method = None
+        else:
+            raise ValueError(f"unknown quantization {quant}")
+        if self.method is None:
+            w = torch.empty(in_features, out_features, dtype=dtype, device=device)
+            w.uniform_(-0.02, 0.02, generator=generator)
+            self.weight = nn.Parameter(w, requires_grad=False)
+            return
+        self.method.create_weights(self, in_features, [out_features], in_features, out_features,
+                                   dtype, device=device)
+        for name in ("qweight", "qzeros"):
+            p = getattr(self, name)
+            p.data = torch.randint(-2**31, 2**31 - 1, p.shape, dtype=torch.int64, device=device,
+                                   generator=generator).to(torch.int32)
+        # scales ~ U(0.5, 1.5) * 1e-2 keeps activations O(1) through the stack
+        s = torch.empty(self.scales.shape, dtype=torch.float32, device=device)
+        s.uniform_(0.5, 1.5, generator=generator)
+        self.scales.data = (s * (1e-2 * (4096.0 / in_features)**0.5)).to(dtype)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if self.method is None:
+            return torch.matmul(x, self.weight)
+        return self.method.apply(self, x)
+
+
+class LlamaDecodeLayer(nn.Module):
+
+    def __init__(self, cfg: LlamaConfig, quant: str, kv_cache_dtype: str, tp: int, device,
+                 generator, dtype):
+        super().__init__()
+        self.cfg = cfg
+        self.hq = cfg.num_attention_heads // tp
+        self.hkv = max(1, cfg.num_key_value_heads // tp)   # replicated when tp > kv heads (llama.py:112-116)
+        d = cfg.head_dim
+        self.q_size, self.kv_size = self.hq * d, self.hkv * d
+        self.input_layernorm = nn.Parameter(torch.ones(cfg.hidden_size, dtype=dtype, device=device),
+                                            requires_grad=False)
+        self.post_attention_layernorm = nn.Parameter(
+            torch.ones(cfg.hidden_size, dtype=dtype, device=device), requires_grad=False)
+        self.qkv_proj = QuantLinear(cfg.hidden_size, self.q_size + 2 * self.kv_size, quant, 128,
+                                    device, generator, dtype)
+        self.o_proj = QuantLinear(self.q_size, cfg.hidden_size, quant, 128, device, generator, dtype)
+        self.gate_up_proj = QuantLinear(cfg.hidden_size, 2 * cfg.intermediate_size // tp, quant, 128,
+                                        device, generator, dtype)
+        self.down_proj = QuantLinear(cfg.intermediate_size // tp, cfg.hidden_size, quant, 128,
+                                     device, generator, dtype)
+        self.attn = Attention(self.hq, d, d**-0.5, self.hkv, kv_cache_dtype=kv_cache_dtype,
+                              dtype=dtype)
+
+    def forward(self, positions, hidden, residual, kv_cache, attn_metadata, cos_sin_cache):
+        eps = self.cfg.rms_norm_eps
+        if residual is None:
+            residual = hidden
+            hidden = rms_norm(hidden, self.input_layernorm, eps)
+        else:
+            residual = hidden + residual
+            hidden = rms_norm(residual, self.input_layernorm, eps)
+        qkv = self.qkv_proj(hidden)
+        q, k, v = qkv.split([self.q_size, self.kv_size, self.kv_size], dim=-1)
+        d = self.cfg.head_dim
+        apply_rotary_neox(positions, q.view(-1, self.hq, d), k.view(-1, self.hkv, d), cos_sin_cache)
+        attn_out = self.attn(q, k, v, kv_cache, attn_metadata)
+        hidden = tensor_model_parallel_all_reduce(self.o_proj(attn_out))
+        residual = hidden + residual
+        hidden = rms_norm(residual, self.post_attention_layernorm, eps)
+        gate_up = self.gate_up_proj(hidden)
+        gate, up = gate_up.chunk(2, dim=-1)
+        hidden = tensor_model_parallel_all_reduce(
+            self.down_proj(torch.nn.functional.silu(gate) * up))
+        return hidden, residual
+
+
+class LlamaDecodeModel(nn.Module):
+
+    def __init__(self, cfg: LlamaConfig, quant: str = "awq", kv_cache_dtype: str = "fp8",
+                 device="cuda", seed: int = 0, dtype=torch.float16):
+        super().__init__()
+        self.cfg, self.dtype = cfg, dtype
+        tp, rank = get_tensor_model_parallel_world_size(), get_tensor_model_parallel_rank()
+        self.tp, self.rank = tp, rank
+        g = torch.Generator(device=device).manual_seed(seed * 1000 + rank)
+        assert cfg.vocab_size % tp == 0 and cfg.num_attention_heads % tp == 0
+        self.vocab_shard = cfg.vocab_size // tp
+        emb = torch.empty(self.vocab_shard, cfg.hidden_size, dtype=dtype, device=device)
+        emb.normal_(0, 1.0, generator=g)
+        self.embed_tokens = nn.Parameter(emb, requires_grad=False)
+        self.layers = nn.ModuleList([
+            LlamaDecodeLayer(cfg, quant, kv_cache_dtype, tp, device, g, dtype)
+            for _ in range(cfg.num_hidden_layers)
+        ])
+        self.norm = nn.Parameter(torch.ones(cfg.hidden_size, dtype=dtype, device=device),
+                                 requires_grad=False)
+        head = torch.empty(cfg.hidden_size, self.vocab_shard, dtype=dtype, device=device)
+        head.normal_(0, 0.02, generator=g)
+        self.lm_head = nn.Parameter(head, requires_grad=False)
+        inv_freq = 1.0 / (cfg.rope_theta**(torch.arange(0, cfg.head_dim, 2, dtype=torch.float32,
+                                                         device=device) / cfg.head_dim))
+        t = torch.arange(cfg.max_position_embeddings, dtype=torch.float32, device=device)
+        freqs = torch.outer(t, inv_freq)
+        self.cos_sin_cache = torch.cat([freqs.cos(), freqs.sin()], dim=-1)  # fp32 [P, D]
+
+    def kv_cache_shape(self, num_blocks: int, block_size: int):
+        layer = self.layers[0]
+        return layer.attn.backend.get_kv_cache_shape(num_blocks, block_size, layer.hkv,
+                                                     self.cfg.head_dim)
+
+    def embed(self, input_ids: torch.Tensor) -> torch.Tensor:
+        """Vocab-parallel lookup + all-reduce (layers/vocab_parallel_embedding.py:90-106)."""
+        if self.tp == 1:
+            return self.embed_tokens[input_ids]
+        lo = self.rank * self.vocab_shard
+        local = input_ids - lo
+        mask = (local < 0) | (local >= self.vocab_shard)
+        out = self.embed_tokens[local.masked_fill(mask, 0)]
+        out.masked_fill_(mask[:, None], 0)
+        return tensor_model_parallel_all_reduce(out)
+
+    def forward(self, input_ids, positions, kv_caches: List[Optional[torch.Tensor]], attn_metadata):
+        hidden = self.embed(input_ids)
+        residual = None
+        for layer, cache in zip(self.layers, kv_caches):
+            hidden, residual = layer(positions, hidden, residual, cache, attn_metadata,
+                                     self.cos_sin_cache)
+        hidden = rms_norm(hidden + residual, self.norm, self.cfg.rms_norm_eps)
+        return hidden
+
+    def compute_logits(self, hidden: torch.Tensor) -> Optional[torch.Tensor]:
+        """Column-parallel lm_head, gathered on rank 0 (layers/logits_processor.py:61-75)."""
+        logits = torch.matmul(hidden, self.lm_head)
+        return tensor_model_parallel_gather(logits, dst=0, dim=-1)
