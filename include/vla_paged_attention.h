@@ -152,6 +152,23 @@ int vla_gptq_gemm(const void* a, const int32_t* qweight, const int32_t* qzeros,
                   const void* scales, const int32_t* b_g_idx, void* out, int m, int size_n,
                   int size_k, int groups, int use_exllama, int bit, void* stream);
 
+/* No counterpart in the reference (its AWQ kernels are CUDA/PTX only,
+ * csrc/quantization/awq/gemm_kernels.cu:204-346): one-time re-layout of an AWQ weight into the
+ * k-packed pair order that gptq_shuffle produces, so that one MFMA kernel serves both formats.
+ *   qweight [in_c, out_c/8], qzeros [in_c/group, out_c/8] (AWQ nibble order) ->
+ *   out_qweight [in_c/8, out_c], out_qzeros [in_c/group, out_c/8] (natural nibble order). */
+int vla_awq_repack(const int32_t* qweight, const int32_t* qzeros, int32_t* out_qweight,
+                   int32_t* out_qzeros, int in_c, int out_c, int group, void* stream);
+
+/* The dequant-GEMM behind awq_gemm / gptq_gemm for k-packed weights (gptq_shuffle'd GPTQ with
+ * zero_offset 1, vla_awq_repack'ed AWQ with zero_offset 0): out[m, n] fp16 = x[m, k] fp16 . W.
+ * workspace (nullable): device scratch of vla_q4_gemm_workspace_bytes() bytes for split-K
+ * partial sums; without it the contraction is not split. k % 64 == 0, group % 32 == 0. */
+int64_t vla_q4_gemm_workspace_bytes(int m, int n, int k, int group);
+int vla_q4_gemm_packed(const void* x, const int32_t* qweight, const int32_t* qzeros,
+                       const void* scales, void* out, int m, int n, int k, int group,
+                       int zero_offset, void* workspace, int64_t workspace_bytes, void* stream);
+
 /* Replaces gptq_shuffle (csrc/ops.h:116; q_gemm.cu:1848-1856), 4 bit, in place.
  *   q_perm [K] int32 or NULL; scratch: device buffer of K/8 * N int32, needed only when q_perm
  *   is given (the reference cudaMalloc's it, q_gemm.cu:1774-1775). */

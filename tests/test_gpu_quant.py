@@ -154,3 +154,58 @@ def test_quant_shape_errors(ops):
                       z((1, 8), dtype=torch.int32, device="cuda"),
                       z((1, 64), dtype=torch.float16, device="cuda"),
                       torch.empty(0, dtype=torch.int32, device="cuda"), True, 8)  # 8-bit
+
+
+def _nib(a, pos):
+    return (a.view(np.uint32) >> (4 * pos)) & 15
+
+
+def test_awq_repack_layout(ops):
+    rng = np.random.default_rng(11)
+    ic, oc, group = 256, 384, 128
+    qw, qz, sc = _awq_weights(rng, ic, oc, group)
+    pw, pz = ops.awq_repack(_cuda(qw), _cuda(qz))
+    torch.cuda.synchronize()
+    pw, pz = pw.cpu().numpy(), pz.cpu().numpy()
+    order = [0, 4, 1, 5, 2, 6, 3, 7]                      # AWQ nibble of column 8j + i
+    pairpos = [0, 4, 1, 5, 2, 6, 3, 7]                    # nibble position of row 8r + e
+    for i in range(8):
+        assert np.array_equal(_nib(pz, i), _nib(qz, order[i]))
+        for e in range(8):
+            assert np.array_equal(_nib(pw[:, i::8], pairpos[e]), _nib(qw[e::8, :], order[i]))
+
+
+@pytest.mark.parametrize("m", [1, 17, 64, 200, 256, 300, 513])
+@pytest.mark.parametrize("ic,oc,group", [(512, 256, 128), (1024, 320, 64), (4096, 6144, 128),
+                                         (14336, 4096, 128)])
+def test_awq_packed_gemm(ops, m, ic, oc, group):
+    if ic >= 4096 and m not in (1, 256, 300):
+        pytest.skip("large shapes only at a few batch sizes")
+    rng = np.random.default_rng(m + ic)
+    qw, qz, sc = _awq_weights(rng, ic, oc, group)
+    x = O.to_bits(rng.uniform(-1, 1, (m, ic)).astype(np.float32), O.DT_F16)
+    pw, pz = ops.awq_repack(_cuda(qw), _cuda(qz))
+    got = ops.q4_gemm_packed(_cuda(x, O.DT_F16), pw, pz, _cuda(sc, O.DT_F16), 0)
+    torch.cuda.synchronize()
+    want = O.gemm_f16(x, O.awq_dequantize(qw, sc, qz))
+    if ic > 4096:  # longer sums: fp16 output of magnitude ~3, allow two ulps
+        np.testing.assert_allclose(got.float().cpu().numpy(), O.from_bits(want, O.DT_F16),
+                                   rtol=3e-3, atol=8e-3)
+    else:
+        _gemm_close(got, want)
+
+
+def test_awq_linear_method_uses_packed_path(ops):
+    from vllm_legacy_amd.quantization.awq import AWQConfig, AWQLinearMethod
+    rng = np.random.default_rng(5)
+    ic, oc, group, m = 512, 256, 128, 33
+    qw, qz, sc = _awq_weights(rng, ic, oc, group)
+    layer = torch.nn.Module()
+    meth = AWQLinearMethod(AWQConfig(4, group))
+    meth.create_weights(layer, ic, [oc], ic, oc, torch.float16, device="cuda")
+    layer.qweight.data, layer.qzeros.data, layer.scales.data = _cuda(qw), _cuda(qz), _cuda(sc, O.DT_F16)
+    x = O.to_bits(rng.uniform(-1, 1, (3, 11, ic)).astype(np.float32), O.DT_F16)
+    out = meth.apply(layer, _cuda(x, O.DT_F16))
+    torch.cuda.synchronize()
+    assert out.shape == (3, 11, oc) and hasattr(layer, "_k_packed")
+    _gemm_close(out.reshape(m, oc), O.gemm_f16(x.reshape(m, ic), O.awq_dequantize(qw, sc, qz)))

@@ -287,6 +287,41 @@ def awq_gemm(input: torch.Tensor, qweight: torch.Tensor, scales: torch.Tensor,
     return out
 
 
+def awq_repack(qweight: torch.Tensor, qzeros: torch.Tensor):
+    """One-time re-layout of an AWQ weight for q4_gemm_packed: returns (qweight [in/8, out],
+    qzeros [in/G, out/8]) in the k-packed pair order (the order gptq_shuffle writes)."""
+    _require_cuda(qweight, qzeros)
+    in_c, qoc = qweight.shape
+    out_c = qoc * 8
+    pw = torch.empty((in_c // 8, out_c), dtype=torch.int32, device=qweight.device)
+    pz = torch.empty_like(qzeros)
+    with torch.cuda.device(qweight.device):
+        check(_lib.lib().vla_awq_repack(qweight.data_ptr(), qzeros.data_ptr(), pw.data_ptr(),
+                                        pz.data_ptr(), in_c, out_c, in_c // qzeros.shape[0],
+                                        _stream(qweight.device)), "awq_repack")
+    return pw, pz
+
+
+def q4_gemm_packed(x: torch.Tensor, qweight: torch.Tensor, qzeros: torch.Tensor,
+                   scales: torch.Tensor, zero_offset: int) -> torch.Tensor:
+    """x [m, k] fp16 times k-packed int4 weights [k/8, n] -> [m, n] fp16."""
+    _require_cuda(x, qweight, qzeros, scales)
+    assert x.dtype == torch.float16 and scales.dtype == torch.float16
+    x = x.contiguous()
+    m, k = x.shape
+    n = qweight.shape[1]
+    group = k // qzeros.shape[0]
+    out = torch.empty((m, n), dtype=x.dtype, device=x.device)
+    L = _lib.lib()
+    ws_bytes = L.vla_q4_gemm_workspace_bytes(m, n, k, group)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device) if ws_bytes else None
+    with torch.cuda.device(x.device):
+        check(L.vla_q4_gemm_packed(x.data_ptr(), qweight.data_ptr(), qzeros.data_ptr(),
+                                   scales.data_ptr(), out.data_ptr(), m, n, k, group, zero_offset,
+                                   _ptr(ws), ws_bytes, _stream(x.device)), "q4_gemm_packed")
+    return out
+
+
 def gptq_gemm(a: torch.Tensor, b_q_weight: torch.Tensor, b_gptq_qzeros: torch.Tensor,
               b_gptq_scales: torch.Tensor, b_g_idx: torch.Tensor, use_exllama: bool,
               bit: int) -> torch.Tensor:
@@ -300,6 +335,8 @@ def gptq_gemm(a: torch.Tensor, b_q_weight: torch.Tensor, b_gptq_qzeros: torch.Te
     if b_g_idx is not None and b_g_idx.device.type != "meta" and b_g_idx.numel() > 0:
         assert b_g_idx.dtype == torch.int32 and b_g_idx.is_cuda
         gidx = b_g_idx
+    if use_exllama and gidx is None and bit == 4 and k % 64 == 0:
+        return q4_gemm_packed(x, b_q_weight, b_gptq_qzeros, b_gptq_scales, 1)
     with torch.cuda.device(x.device):
         check(_lib.lib().vla_gptq_gemm(x.data_ptr(), b_q_weight.data_ptr(),
                                        b_gptq_qzeros.data_ptr(), b_gptq_scales.data_ptr(),

@@ -24,7 +24,8 @@ EXPORTS = [
     "vla_kv_dtype_from_string", "vla_paged_attention_v1", "vla_paged_attention_v2",
     "vla_reshape_and_cache", "vla_copy_blocks", "vla_swap_blocks", "vla_convert_fp8",
     "vla_awq_dequantize", "vla_awq_gemm", "vla_gptq_dequantize", "vla_gptq_gemm",
-    "vla_gptq_shuffle", "vla_get_max_shared_memory_per_block",
+    "vla_gptq_shuffle", "vla_get_max_shared_memory_per_block", "vla_awq_repack",
+    "vla_q4_gemm_workspace_bytes", "vla_q4_gemm_packed",
 ]
 
 
@@ -64,6 +65,10 @@ def lib():
         L.vla_gptq_gemm.argtypes = [p, p, p, p, p, p, i, i, i, i, i, i, p]
         L.vla_gptq_shuffle.argtypes = [p, p, p, i, i, i, p]
         L.vla_get_max_shared_memory_per_block.argtypes = [i]
+        L.vla_awq_repack.argtypes = [p, p, p, p, i, i, i, p]
+        L.vla_q4_gemm_workspace_bytes.argtypes = [i, i, i, i]
+        L.vla_q4_gemm_workspace_bytes.restype = i64
+        L.vla_q4_gemm_packed.argtypes = [p, p, p, p, p, i, i, i, i, i, p, i64, p]
         _lib = L
     return _lib
 

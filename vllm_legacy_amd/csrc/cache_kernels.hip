@@ -138,9 +138,14 @@ __global__ __launch_bounds__(256) void convert_fp8_kernel(void* __restrict__ dst
     if constexpr (TO_FP8)
       reinterpret_cast<uint8_t*>(dst)[i] =
           fp8_e4m3_encode(S::to_f32(reinterpret_cast<const T*>(src)[i]) / scale);
-    else
-      reinterpret_cast<T*>(dst)[i] =
-          S::from_f32(fp8_e4m3_decode(reinterpret_cast<const uint8_t*>(src)[i]) * scale);
+    else {
+      const uint8_t b = reinterpret_cast<const uint8_t*>(src)[i];
+      T r = S::from_f32(fp8_e4m3_decode(b) * scale);
+      // keep the sign of the -0 code: the multiply is fused into a mixed-precision fma with a
+      // +0 addend, which turns -0 into +0
+      if (b == 0x80) r = S::from_f32(-0.0f);
+      reinterpret_cast<T*>(dst)[i] = r;
+    }
   }
 }
 

@@ -296,6 +296,9 @@ extern "C" int vla_gptq_gemm(const void* a, const int32_t* qweight, const int32_
   if (m == 0) return VLA_OK;
   const int gs = size_k / groups;
   hipStream_t s = (hipStream_t)stream;
+  if (use_exllama && !b_g_idx && size_k % 64 == 0 && gs % 32 == 0)
+    return vla_q4_gemm_packed(a, qweight, qzeros, scales, out, m, size_n, size_k, gs, 1, nullptr,
+                              0, stream);
   if (use_exllama)
     return launch_gemm<kGptqShuffled>(a, qweight, qzeros, scales, b_g_idx, out, m, size_n, size_k,
                                       gs, s);

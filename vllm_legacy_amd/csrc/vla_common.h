@@ -60,8 +60,7 @@ __device__ __forceinline__ f32x2 fp8x2_to_f32(uint32_t w) {
   return __builtin_amdgcn_cvt_pk_f32_fp8(w, HI);
 }
 __device__ __forceinline__ float fp8_e4m3_decode(uint8_t b) {
-  const float v = fp8x2_to_f32<false>((uint32_t)b)[0];
-  return b == 0x80 ? -0.0f : v;  // the hardware converter returns +0 for the -0 code
+  return fp8x2_to_f32<false>((uint32_t)b)[0];
 }
 
 // four fp8 bytes -> four 16-bit floats, exact (every e4m3fn value is representable in both

@@ -72,6 +72,14 @@ class AWQLinearMethod:
         x2 = x.reshape(-1, x.shape[-1])
         if DEQUANT_MATMUL_MIN_TOKENS is not None and x2.shape[0] >= DEQUANT_MATMUL_MIN_TOKENS:
             out = torch.matmul(x2, ops.awq_dequantize(qweight, scales, qzeros, 0, 0, 0))
+        elif x2.shape[1] % 64 == 0:
+            # one-time re-layout on the first forward pass, as the reference does for GPTQ's
+            # exllama kernels (quantization/gptq.py:209-217)
+            packed = getattr(layer, "_k_packed", None)
+            if packed is None:
+                packed = ops.awq_repack(qweight, qzeros)
+                layer._k_packed = packed
+            out = ops.q4_gemm_packed(x2, packed[0], packed[1], scales, 0)
         else:
             out = ops.awq_gemm(x2, qweight, scales, qzeros, self.quant_config.pack_factor)
         if bias is not None:
