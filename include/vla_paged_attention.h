@@ -175,6 +175,33 @@ int vla_q4_gemm_packed(const void* x, const int32_t* qweight, const int32_t* qze
 int vla_gptq_shuffle(int32_t* qweight, const int32_t* q_perm, int32_t* scratch, int size_k,
                      int size_n, int bit, void* stream);
 
+/* ---- the elementwise steps next to attention in a decoder layer ----------------------------- */
+
+/* Replaces rms_norm (csrc/ops.h:32-33; csrc/layernorm_kernels.cu:22-46, :291-310):
+ * out[t, :] = model_dtype(x * rsqrt(mean(x^2) + eps)) * weight; rows of hidden_size elements,
+ * 16-byte aligned. */
+int vla_rms_norm(void* out, const void* input, const void* weight, float epsilon, int num_tokens,
+                 int hidden_size, int dtype, void* stream);
+
+/* Replaces fused_add_rms_norm (csrc/ops.h:35-36; csrc/layernorm_kernels.cu:254-289), in place:
+ * residual = input + residual; input = rms_norm(residual) * weight. */
+int vla_fused_add_rms_norm(void* input, void* residual, const void* weight, float epsilon,
+                           int num_tokens, int hidden_size, int dtype, void* stream);
+
+/* Replaces rotary_embedding (csrc/ops.h:38-40; csrc/pos_encoding_kernels.cu:10-93, :130-165),
+ * in place on query [num_tokens, num_heads, head_size] and key [num_tokens, num_kv_heads,
+ * head_size] (token strides in elements); positions int64 [num_tokens]; cos_sin_cache
+ * [max_position, rot_dim] model dtype (cos half then sin half). */
+int vla_rotary_embedding(const int64_t* positions, void* query, void* key,
+                         const void* cos_sin_cache, int num_tokens, int num_heads,
+                         int num_kv_heads, int head_size, int rot_dim, int64_t query_stride,
+                         int64_t key_stride, int is_neox, int dtype, void* stream);
+
+/* Replaces silu_and_mul (csrc/ops.h:48; csrc/activation_kernels.cu:14-33, :62-77):
+ * out[t, :d] = silu(input[t, :d]) * input[t, d:2d]. */
+int vla_silu_and_mul(void* out, const void* input, int num_tokens, int d, int dtype,
+                     void* stream);
+
 /* Replaces get_max_shared_memory_per_block_device_attribute
  * (csrc/cuda_utils_kernels.cu:17-29). Returns bytes, or -1. */
 int vla_get_max_shared_memory_per_block(int device);

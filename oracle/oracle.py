@@ -237,5 +237,48 @@ def gemm_f16(a_bits, w_bits, a_perm=None):
     return out
 
 
+# ------------------------------------------------------------------ layer glue
+
+
+def rms_norm(x, weight, eps, dt):
+    x = _c(np.ascontiguousarray(x))
+    out = np.empty_like(x)
+    lib().oracle_rms_norm(_p(out), _p(x), None, _p(_c(weight)), C.c_float(eps),
+                          C.c_int(x.size // x.shape[-1]), C.c_int(x.shape[-1]), C.c_int(dt),
+                          C.c_int(0))
+    return out
+
+
+def fused_add_rms_norm(x, residual, weight, eps, dt):
+    """Returns (new_input, new_residual)."""
+    x, r = np.ascontiguousarray(x).copy(), np.ascontiguousarray(residual).copy()
+    lib().oracle_rms_norm(None, _p(x), _p(r), _p(_c(weight)), C.c_float(eps),
+                          C.c_int(x.size // x.shape[-1]), C.c_int(x.shape[-1]), C.c_int(dt),
+                          C.c_int(1))
+    return x, r
+
+
+def rotary_embedding(positions, query, key, head_size, cos_sin_cache, is_neox, dt):
+    """query [T, Hq*D], key [T, Hkv*D] contiguous storage arrays; returns rotated copies."""
+    q, k = np.ascontiguousarray(query).copy(), np.ascontiguousarray(key).copy()
+    pos = np.ascontiguousarray(positions, dtype=np.int64)
+    T = pos.size
+    q2, k2 = q.reshape(T, -1), k.reshape(T, -1)
+    lib().oracle_rotary_embedding(_p(pos), _p(q), _p(k), _p(_c(cos_sin_cache)), C.c_int(T),
+                                  C.c_int(q2.shape[1] // head_size),
+                                  C.c_int(k2.shape[1] // head_size), C.c_int(head_size),
+                                  C.c_int(cos_sin_cache.shape[1]), C.c_int64(q2.shape[1]),
+                                  C.c_int64(k2.shape[1]), C.c_int(1 if is_neox else 0), C.c_int(dt))
+    return q, k
+
+
+def silu_and_mul(x, dt):
+    x = _c(np.ascontiguousarray(x))
+    d = x.shape[-1] // 2
+    out = np.empty(x.shape[:-1] + (d, ), dtype=x.dtype)
+    lib().oracle_silu_and_mul(_p(out), _p(x), C.c_int(x.size // (2 * d)), C.c_int(d), C.c_int(dt))
+    return out
+
+
 def num_threads() -> int:
     return lib().oracle_num_threads()

@@ -488,6 +488,68 @@ void oracle_gemm_f16(const uint16_t* a, const uint16_t* w, uint16_t* c, int m, i
   }
 }
 
+/* ------------------------------------------------------------ layer glue (next to attention) */
+
+/* rms_norm / fused_add_rms_norm (csrc/layernorm_kernels.cu:22-46, :254-289). fused != 0:
+ * residual = round(input + residual) first and the result goes to `input`; else out = norm(input). */
+void oracle_rms_norm(void* out, void* input, void* residual, const void* weight, float eps,
+                     int num_tokens, int hidden, int dt, int fused) {
+  for (int64_t t = 0; t < num_tokens; ++t) {
+    float var = 0.f;
+    for (int i = 0; i < hidden; ++i) {
+      float x = load_scalar(input, t * hidden + i, dt);
+      if (fused) {
+        x = round_scalar(x + load_scalar(residual, t * hidden + i, dt), dt);
+        store_scalar(residual, t * hidden + i, dt, x);
+      }
+      var += x * x;
+    }
+    float inv = 1.0f / sqrtf(var / (float)hidden + eps);
+    for (int i = 0; i < hidden; ++i) {
+      float x = load_scalar(fused ? residual : input, t * hidden + i, dt);
+      float y = round_scalar(round_scalar(x * inv, dt) * load_scalar(weight, i, dt), dt);
+      store_scalar(fused ? input : out, t * hidden + i, dt, y);
+    }
+  }
+}
+
+/* rotary_embedding (csrc/pos_encoding_kernels.cu:10-93): scalar_t arithmetic, i.e. every
+ * product and every sum rounded to the model dtype. */
+void oracle_rotary_embedding(const int64_t* positions, void* query, void* key,
+                             const void* cos_sin_cache, int num_tokens, int num_heads,
+                             int num_kv_heads, int head_size, int rot_dim, int64_t q_stride,
+                             int64_t k_stride, int is_neox, int dt) {
+  int embed = rot_dim / 2;
+  for (int64_t t = 0; t < num_tokens; ++t) {
+    int64_t cb = positions[t] * rot_dim;
+    for (int pass = 0; pass < 2; ++pass) {
+      void* arr = pass ? key : query;
+      int nh = pass ? num_kv_heads : num_heads;
+      int64_t stride = pass ? k_stride : q_stride;
+      for (int h = 0; h < nh; ++h)
+        for (int o = 0; o < embed; ++o) {
+          int64_t base = t * stride + (int64_t)h * head_size;
+          int xi = is_neox ? o : 2 * o, yi = is_neox ? embed + o : 2 * o + 1;
+          float c = load_scalar(cos_sin_cache, cb + o, dt);
+          float s = load_scalar(cos_sin_cache, cb + embed + o, dt);
+          float x = load_scalar(arr, base + xi, dt), y = load_scalar(arr, base + yi, dt);
+          store_scalar(arr, base + xi, dt, round_scalar(x * c, dt) - round_scalar(y * s, dt));
+          store_scalar(arr, base + yi, dt, round_scalar(y * c, dt) + round_scalar(x * s, dt));
+        }
+    }
+  }
+}
+
+/* silu_and_mul (csrc/activation_kernels.cu:14-33): out = T(x / (1 + exp(-x))) * y. */
+void oracle_silu_and_mul(void* out, const void* input, int num_tokens, int d, int dt) {
+  for (int64_t t = 0; t < num_tokens; ++t)
+    for (int i = 0; i < d; ++i) {
+      float x = load_scalar(input, t * 2 * d + i, dt), y = load_scalar(input, t * 2 * d + d + i, dt);
+      float a = round_scalar(x / (1.0f + expf(-x)), dt);
+      store_scalar(out, t * d + i, dt, a * y);
+    }
+}
+
 int oracle_num_threads(void) {
 #ifdef _OPENMP
   return omp_get_max_threads();

@@ -42,6 +42,59 @@ def _require_cuda(*ts):
             raise RuntimeError("expected a tensor on the GPU")
 
 
+# ---------------------------------------------------------------- layer glue
+# (vllm/_custom_ops.py:16-17 silu_and_mul, :103-112 rotary_embedding, :126-133 layer norms)
+
+
+def silu_and_mul(out: torch.Tensor, x: torch.Tensor) -> None:
+    _require_cuda(out, x)
+    d = x.shape[-1] // 2
+    assert x.is_contiguous() and out.is_contiguous() and out.shape[-1] == d
+    with torch.cuda.device(x.device):
+        check(_lib.lib().vla_silu_and_mul(out.data_ptr(), x.data_ptr(), x.numel() // (2 * d), d,
+                                          _dt(x), _stream(x.device)), "silu_and_mul")
+
+
+def rotary_embedding(positions: torch.Tensor, query: torch.Tensor, key: torch.Tensor,
+                     head_size: int, cos_sin_cache: torch.Tensor, is_neox: bool) -> None:
+    """In place on query [T, Hq * D] and key [T, Hkv * D] (or [T, H, D]); rows may be strided."""
+    _require_cuda(positions, query, key, cos_sin_cache)
+    assert positions.dtype == torch.int64 and positions.is_contiguous()
+    assert cos_sin_cache.dtype == query.dtype and cos_sin_cache.is_contiguous()
+    num_tokens = positions.numel()
+    q2, k2 = query.view(num_tokens, -1), key.view(num_tokens, -1)
+    assert q2.stride(1) == 1 and k2.stride(1) == 1
+    with torch.cuda.device(query.device):
+        check(_lib.lib().vla_rotary_embedding(
+            positions.data_ptr(), query.data_ptr(), key.data_ptr(), cos_sin_cache.data_ptr(),
+            num_tokens, q2.shape[1] // head_size, k2.shape[1] // head_size, head_size,
+            cos_sin_cache.shape[1], q2.stride(0), k2.stride(0), 1 if is_neox else 0, _dt(query),
+            _stream(query.device)), "rotary_embedding")
+
+
+def rms_norm(out: torch.Tensor, input: torch.Tensor, weight: torch.Tensor,
+             epsilon: float) -> None:
+    _require_cuda(out, input, weight)
+    assert input.is_contiguous() and out.is_contiguous() and weight.is_contiguous()
+    h = input.shape[-1]
+    with torch.cuda.device(input.device):
+        check(_lib.lib().vla_rms_norm(out.data_ptr(), input.data_ptr(), weight.data_ptr(), epsilon,
+                                      input.numel() // h, h, _dt(input), _stream(input.device)),
+              "rms_norm")
+
+
+def fused_add_rms_norm(input: torch.Tensor, residual: torch.Tensor, weight: torch.Tensor,
+                       epsilon: float) -> None:
+    _require_cuda(input, residual, weight)
+    assert input.is_contiguous() and residual.is_contiguous() and weight.is_contiguous()
+    h = input.shape[-1]
+    with torch.cuda.device(input.device):
+        check(_lib.lib().vla_fused_add_rms_norm(input.data_ptr(), residual.data_ptr(),
+                                                weight.data_ptr(), epsilon, input.numel() // h, h,
+                                                _dt(input), _stream(input.device)),
+              "fused_add_rms_norm")
+
+
 # ---------------------------------------------------------------- paged attention
 
 

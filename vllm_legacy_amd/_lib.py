@@ -25,7 +25,8 @@ EXPORTS = [
     "vla_reshape_and_cache", "vla_copy_blocks", "vla_swap_blocks", "vla_convert_fp8",
     "vla_awq_dequantize", "vla_awq_gemm", "vla_gptq_dequantize", "vla_gptq_gemm",
     "vla_gptq_shuffle", "vla_get_max_shared_memory_per_block", "vla_awq_repack",
-    "vla_q4_gemm_workspace_bytes", "vla_q4_gemm_packed",
+    "vla_q4_gemm_workspace_bytes", "vla_q4_gemm_packed", "vla_rms_norm",
+    "vla_fused_add_rms_norm", "vla_rotary_embedding", "vla_silu_and_mul",
 ]
 
 
@@ -69,6 +70,10 @@ def lib():
         L.vla_q4_gemm_workspace_bytes.argtypes = [i, i, i, i]
         L.vla_q4_gemm_workspace_bytes.restype = i64
         L.vla_q4_gemm_packed.argtypes = [p, p, p, p, p, i, i, i, i, i, p, i64, p]
+        L.vla_rms_norm.argtypes = [p, p, p, f, i, i, i, p]
+        L.vla_fused_add_rms_norm.argtypes = [p, p, p, f, i, i, i, p]
+        L.vla_rotary_embedding.argtypes = [p, p, p, p, i, i, i, i, i, i64, i64, i, i, p]
+        L.vla_silu_and_mul.argtypes = [p, p, i, i, i, p]
         _lib = L
     return _lib
 

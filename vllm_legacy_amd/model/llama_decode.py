@@ -4,9 +4,8 @@ Shapes and layer order follow the reference's vllm/model_executor/models/llama.p
 (qkv_proj -> rotary -> attention -> o_proj, gate_up_proj -> SiluAndMul -> down_proj, Megatron
 column/row sharding with an all-reduce after each row-parallel linear,
 vllm/model_executor/layers/linear.py:755-779).  The int4 linears and the attention (cache write +
-paged attention) run on the gfx950 library; RMSNorm, rotary embedding, SwiGLU, the embedding
-lookup and the fp16 lm_head are plain PyTorch-ROCm ops (they are outside this backend's scope and
-stand in for the reference's own kernels).
+paged attention), RMSNorm, rotary embedding and SwiGLU run on the gfx950 library; the embedding
+lookup and the fp16 lm_head are plain PyTorch-ROCm ops.
 
 Weights are random (no checkpoints are available offline); this module exists to drive the
 decode-step benchmark and the tensor-parallel tests, not to load models.
@@ -22,6 +21,7 @@ from vllm_legacy_amd.distributed.communication_op import (tensor_model_parallel_
                                                           tensor_model_parallel_gather)
 from vllm_legacy_amd.distributed.parallel_state import (get_tensor_model_parallel_rank,
                                                         get_tensor_model_parallel_world_size)
+from vllm_legacy_amd.layers import RMSNorm, RotaryEmbedding, SiluAndMul
 from vllm_legacy_amd.quantization.awq import AWQConfig, AWQLinearMethod
 from vllm_legacy_amd.quantization.gptq import GPTQConfig, GPTQLinearMethod
 
@@ -53,25 +53,6 @@ class LlamaConfig:
         return LlamaConfig(hidden_size=256, intermediate_size=512, num_hidden_layers=2,
                            num_attention_heads=8, num_key_value_heads=2, head_dim=32 * 2,
                            vocab_size=1024, max_position_embeddings=512)
-
-
-def rms_norm(x: torch.Tensor, weight: torch.Tensor, eps: float) -> torch.Tensor:
-    v = x.float()
-    v = v * torch.rsqrt(v.pow(2).mean(-1, keepdim=True) + eps)
-    return v.to(x.dtype) * weight
-
-
-def apply_rotary_neox(positions: torch.Tensor, q: torch.Tensor, k: torch.Tensor,
-                      cos_sin_cache: torch.Tensor) -> None:
-    """In-place NeoX-style rotation of q [T, Hq, D] and k [T, Hkv, D]
-    (csrc/pos_encoding_kernels.cu:71-93 semantics)."""
-    cs = cos_sin_cache[positions]                    # [T, D]
-    half = cs.shape[-1] // 2
-    cos, sin = cs[:, None, :half], cs[:, None, half:]
-    for t in (q, k):
-        x1, x2 = t[..., :half].clone(), t[..., half:].clone()
-        t[..., :half] = (x1 * cos - x2 * sin).to(t.dtype)
-        t[..., half:] = (x2 * cos + x1 * sin).to(t.dtype)
 
 
 class QuantLinear(nn.Module):
@@ -121,10 +102,9 @@ class LlamaDecodeLayer(nn.Module):
         self.hkv = max(1, cfg.num_key_value_heads // tp)   # replicated when tp > kv heads (llama.py:112-116)
         d = cfg.head_dim
         self.q_size, self.kv_size = self.hq * d, self.hkv * d
-        self.input_layernorm = nn.Parameter(torch.ones(cfg.hidden_size, dtype=dtype, device=device),
-                                            requires_grad=False)
-        self.post_attention_layernorm = nn.Parameter(
-            torch.ones(cfg.hidden_size, dtype=dtype, device=device), requires_grad=False)
+        self.input_layernorm = RMSNorm(cfg.hidden_size, cfg.rms_norm_eps, dtype, device)
+        self.post_attention_layernorm = RMSNorm(cfg.hidden_size, cfg.rms_norm_eps, dtype, device)
+        self.act_fn = SiluAndMul()
         self.qkv_proj = QuantLinear(cfg.hidden_size, self.q_size + 2 * self.kv_size, quant, 128,
                                     device, generator, dtype)
         self.o_proj = QuantLinear(self.q_size, cfg.hidden_size, quant, 128, device, generator, dtype)
@@ -135,26 +115,21 @@ class LlamaDecodeLayer(nn.Module):
         self.attn = Attention(self.hq, d, d**-0.5, self.hkv, kv_cache_dtype=kv_cache_dtype,
                               dtype=dtype)
 
-    def forward(self, positions, hidden, residual, kv_cache, attn_metadata, cos_sin_cache):
-        eps = self.cfg.rms_norm_eps
+    def forward(self, positions, hidden, residual, kv_cache, attn_metadata, rotary_emb):
+        # layer order of vllm/model_executor/models/llama.py:196-224
         if residual is None:
             residual = hidden
-            hidden = rms_norm(hidden, self.input_layernorm, eps)
+            hidden = self.input_layernorm(hidden)
         else:
-            residual = hidden + residual
-            hidden = rms_norm(residual, self.input_layernorm, eps)
+            hidden, residual = self.input_layernorm(hidden, residual)
         qkv = self.qkv_proj(hidden)
         q, k, v = qkv.split([self.q_size, self.kv_size, self.kv_size], dim=-1)
-        d = self.cfg.head_dim
-        apply_rotary_neox(positions, q.view(-1, self.hq, d), k.view(-1, self.hkv, d), cos_sin_cache)
+        rotary_emb(positions, q, k)     # in place on the strided views of qkv
         attn_out = self.attn(q, k, v, kv_cache, attn_metadata)
         hidden = tensor_model_parallel_all_reduce(self.o_proj(attn_out))
-        residual = hidden + residual
-        hidden = rms_norm(residual, self.post_attention_layernorm, eps)
-        gate_up = self.gate_up_proj(hidden)
-        gate, up = gate_up.chunk(2, dim=-1)
+        hidden, residual = self.post_attention_layernorm(hidden, residual)
         hidden = tensor_model_parallel_all_reduce(
-            self.down_proj(torch.nn.functional.silu(gate) * up))
+            self.down_proj(self.act_fn(self.gate_up_proj(hidden))))
         return hidden, residual
 
 
@@ -176,16 +151,12 @@ class LlamaDecodeModel(nn.Module):
             LlamaDecodeLayer(cfg, quant, kv_cache_dtype, tp, device, g, dtype)
             for _ in range(cfg.num_hidden_layers)
         ])
-        self.norm = nn.Parameter(torch.ones(cfg.hidden_size, dtype=dtype, device=device),
-                                 requires_grad=False)
+        self.norm = RMSNorm(cfg.hidden_size, cfg.rms_norm_eps, dtype, device)
         head = torch.empty(cfg.hidden_size, self.vocab_shard, dtype=dtype, device=device)
         head.normal_(0, 0.02, generator=g)
         self.lm_head = nn.Parameter(head, requires_grad=False)
-        inv_freq = 1.0 / (cfg.rope_theta**(torch.arange(0, cfg.head_dim, 2, dtype=torch.float32,
-                                                         device=device) / cfg.head_dim))
-        t = torch.arange(cfg.max_position_embeddings, dtype=torch.float32, device=device)
-        freqs = torch.outer(t, inv_freq)
-        self.cos_sin_cache = torch.cat([freqs.cos(), freqs.sin()], dim=-1)  # fp32 [P, D]
+        self.rotary_emb = RotaryEmbedding(cfg.head_dim, cfg.head_dim, cfg.max_position_embeddings,
+                                          cfg.rope_theta, True, dtype, device)
 
     def kv_cache_shape(self, num_blocks: int, block_size: int):
         layer = self.layers[0]
@@ -208,8 +179,8 @@ class LlamaDecodeModel(nn.Module):
         residual = None
         for layer, cache in zip(self.layers, kv_caches):
             hidden, residual = layer(positions, hidden, residual, cache, attn_metadata,
-                                     self.cos_sin_cache)
-        hidden = rms_norm(hidden + residual, self.norm, self.cfg.rms_norm_eps)
+                                     self.rotary_emb)
+        hidden, _ = self.norm(hidden, residual)
         return hidden
 
     def compute_logits(self, hidden: torch.Tensor) -> Optional[torch.Tensor]:
