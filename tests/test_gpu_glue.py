@@ -3,7 +3,8 @@ rotary embedding, SwiGLU gating).  Shapes follow the reference's tests
 (tests/kernels/test_layernorm.py, test_pos_encoding.py, test_activation.py: tokens 7/83/4096,
 hidden 768..8199, head sizes 64..256); expectations come from the oracle's restatement of the CUDA
 kernels' rounding order.  Rotary is compared bit for bit; the norms and SiLU within one unit of
-the model dtype's last place (rsqrt / exp differ between libm and the GPU)."""
+the model dtype's last place (rsqrt / exp differ between libm and the GPU; for float32 the bound
+is 4e-6 relative, which also covers the different summation order of the variance)."""
 import numpy as np
 import pytest
 import torch
@@ -13,7 +14,7 @@ from tests import pa_testlib as T
 
 pytestmark = pytest.mark.gpu
 DTYPES = [O.DT_F16, O.DT_BF16, O.DT_F32]
-ULP = {O.DT_F16: 2.0**-10, O.DT_BF16: 2.0**-7, O.DT_F32: 2.0**-22}
+ULP = {O.DT_F16: 2.0**-10, O.DT_BF16: 2.0**-7, O.DT_F32: 2.0**-19}
 
 
 @pytest.fixture(scope="module")
