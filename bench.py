@@ -260,6 +260,19 @@ def main():
         attn_ms = sum(a.elapsed_time(b_) for a, b_ in evs) / len(evs)
     achieved = algo_bytes / (attn_ms * 1e-3) / 1e9
 
+    # HBM bytes per launch from the committed PMC passes, when they were taken on this workload
+    traffic = None
+    try:
+        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles",
+                               "attn_traffic.json")) as f:
+            rec = json.load(f)
+        w = rec["workload"]
+        if (w["batch"], w["seq"], w["kv"], w["num_heads"], w["num_kv_heads"], w["head_size"],
+                w["block_size"]) == (B, S, args.kv, hq, hkv, d, BS):
+            traffic = rec["fetch_bytes"] + rec["write_bytes"]
+    except (OSError, KeyError, ValueError):
+        pass
+
     if rank == 0:
         result = {
             "metric": "decode tokens/s, Llama-3-8B AWQ-int4 fp8-KV, bs=256 seq=4k (+ achieved HBM GB/s of paged attention in `roofline`)",
@@ -289,7 +302,7 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
-                "traffic": None,
+                "traffic": traffic,
                 "algorithmic_bytes_per_launch": algo_bytes,
                 "launch_ms": round(attn_ms, 4),
                 "attention_share_of_step": round(attn_ms * len(caches) / ms_per_step, 3),
