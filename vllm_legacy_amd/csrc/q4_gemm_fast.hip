@@ -17,6 +17,9 @@
 // through LDS in full 128-byte rows (XOR-swizzled 16-byte chunks, conflict-free ds_read_b128),
 // double buffered, one barrier per K step; weight words, zeros and scales go global -> registers.
 // Small-N layers are split along K into fp32 slabs that a second kernel sums.
+#include <cstdio>
+#include <cstdlib>
+
 #include "vla_common.h"
 
 namespace vla {
@@ -183,6 +186,206 @@ __global__ __launch_bounds__(kThreadsG, 2) void q4_gemm_fast_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Main kernel: 32x32x16 MFMAs, wave tile 128 (M) x 32 (N), workgroup = NW waves side by side
+// along N, i.e. a 128 x 32*NW output tile, K step 64.  Every wave owns its columns outright, so
+// no weight is dequantised twice in a workgroup, and per K step a wave spends 52 vector ops on
+// its 4 words per lane for 16 MFMAs of 32 cycles.  A 128-row tile also halves the bytes of x a
+// workgroup pulls from L2 per flop against a 256-row tile of the same area (x is re-read by every
+// column tile; the int4 weights are the small operand).
+// Lane l: c = l & 31 is its column (B) / row within a 32-row tile (A), h = l >> 5 picks k 8h..8h+7
+// of a 16-deep slice.  Weight words (with their group's zeros and scales) are fetched three K
+// steps ahead into a four-name register ring, x two steps ahead into two register sets and parked
+// in the LDS double buffer one step ahead; A fragments are read one slice ahead of their MFMAs.
+// Requires group_size % 64 == 0.
+// LDS x image: row r (128 bytes = 8 chunks of 16), chunk q stored at slot q ^ ((r >> 1) & 7):
+// with rows on lanes this keeps every ds_read_b128 lane group on 16 distinct 16-byte slots.
+constexpr int TM2 = 128;
+constexpr int X2_TILE_BYTES = TM2 * TK * 2;  // 16 KiB per buffer
+
+template <int ZOFF, bool SPLIT, int NW>
+__global__ __launch_bounds__(64 * NW) void q4_gemm_m32_kernel(
+    const _Float16* __restrict__ x, const uint32_t* __restrict__ qw,
+    const uint32_t* __restrict__ qz, const _Float16* __restrict__ scales, void* __restrict__ outp,
+    int m, int n, int k, int group_size, int k_per_split) {
+  constexpr int THREADS = 64 * NW;
+  constexpr int XCH = (TM2 * 8) / THREADS;  // 16-byte chunks of the x tile per thread
+  constexpr int XROWS = THREADS / 8;        // rows covered by one pass of the staging threads
+  __shared__ __attribute__((aligned(16))) unsigned char xs[2 * X2_TILE_BYTES];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wn = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h = lane >> 5, c = lane & 31;
+  const int n0 = blockIdx.x * (32 * NW), m0 = blockIdx.y * TM2;
+  const int k_begin = blockIdx.z * k_per_split;
+  const int k_end = min(k, k_begin + k_per_split);
+  const int nsteps = (k_end - k_begin) / TK;
+  if (nsteps <= 0) return;
+
+  // ---- x staging: thread -> (row = XROWS i + tid / 8, chunk tid % 8).  Rows past m are clamped
+  // to the last row: they only feed accumulator rows that are never stored.
+  const int srow = tid >> 3, schunk = tid & 7;
+  const _Float16* xsrc[XCH];
+#pragma unroll
+  for (int i = 0; i < XCH; ++i)
+    xsrc[i] = x + (int64_t)min(m0 + srow + XROWS * i, m - 1) * k + 8 * schunk;
+  struct XSet { u32x4 v[XCH]; };
+  auto load_x = [&](int step, XSet& d) {
+    const int k0 = k_begin + min(step, nsteps - 1) * TK;   // past the end: re-read the last step
+#pragma unroll
+    for (int i = 0; i < XCH; ++i) d.v[i] = *reinterpret_cast<const u32x4*>(xsrc[i] + k0);
+  };
+  auto store_x = [&](int buf, const XSet& d) {
+#pragma unroll
+    for (int i = 0; i < XCH; ++i) {
+      const int r = srow + XROWS * i;
+      *reinterpret_cast<u32x4*>(xs + buf * X2_TILE_BYTES + r * 128 +
+                                ((schunk ^ ((r >> 1) & 7)) << 4)) = d.v[i];
+    }
+  };
+
+  // ---- weights: lane (h, c) owns column ncol; per 16-deep slice s one word, row k0/8 + 2s + h
+  const int ncol = n0 + 32 * wn + c;
+  const bool nok = ncol < n;
+  const int ncl = nok ? ncol : 0;                    // clamped: loads stay in bounds, result unused
+  const uint32_t* wsrc = qw + (int64_t)h * n + ncl;
+  const uint32_t* zsrc = qz + (ncl >> 3);
+  // scales are fetched as the aligned 32-bit word holding columns (ncl & ~1, ncl | 1): a 16-bit
+  // load would be widened by an ALU instruction that has to wait for it
+  const uint32_t* ssrc = reinterpret_cast<const uint32_t*>(scales) + (ncl >> 1);
+  const int zshift = 4 * (ncl & 7);
+  const uint32_t ssel = (ncl & 1) ? 0x03020302u : 0x01000100u;
+  struct WStep { uint32_t w[4]; uint32_t z; uint32_t s; };  // s: the scale pair word
+  auto load_w = [&](int step, WStep& d) {
+    step = min(step, nsteps - 1);
+    const int k0 = k_begin + step * TK;
+    const uint32_t* p = wsrc + (int64_t)(k0 >> 3) * n;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) d.w[s] = p[(int64_t)(2 * s) * n];
+    const int grp = k0 / group_size;
+    d.z = zsrc[(int64_t)grp * (n >> 3)];
+    d.s = ssrc[(int64_t)grp * (n >> 1)];
+  };
+
+  f32x16 acc[4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[a][i] = 0.f;
+
+  const f16x2 sixteenth = {(_Float16)0.0625f, (_Float16)0.0625f};
+
+  // One K step t: issue the loads of x(t+2) into `xnew` and of the weights of step t+3 into
+  // `wnew`, compute step t from `wcur` and LDS buffer t & 1, then park x(t+1) (`xpark`, loaded
+  // a step ago) in the other buffer.  Register sets rotate by NAME (the loop is unrolled by
+  // four), so a register that a load is still writing is never copied.
+  auto k_step = [&](int t, const WStep& wcur, WStep& wnew, XSet& xnew, const XSet& xpark) {
+    const int buf = t & 1;
+    load_x(t + 2, xnew);
+    load_w(t + 3, wnew);
+    __builtin_amdgcn_sched_barrier(0);               // keep the loads at the top of the step
+
+    // -(1024 + z) and -(64 + z) as fp16 bit patterns (ulp is 1 resp. 1/16 there, z <= 16)
+    const uint32_t z = ((wcur.z >> zshift) & 15u) + ZOFF;
+    const f16x2 zc1 = as_h2((z * 0x00010001u) | 0xE400E400u);
+    const f16x2 zc2 = as_h2((z * 0x00100010u) | 0xD400D400u);
+    const f16x2 sc2 = as_h2(__builtin_amdgcn_perm(wcur.s, wcur.s, ssel));
+
+    const unsigned char* xb = xs + buf * X2_TILE_BYTES;
+    auto read_a = [&](int s, u32x4 (&af)[4]) {
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        const int row = 32 * a + c;
+        af[a] = *reinterpret_cast<const u32x4*>(
+            xb + row * 128 + (((2 * s + h) ^ ((row >> 1) & 7)) << 4));
+      }
+    };
+    auto dequant = [&](int s) {
+      const uint32_t w = wcur.w[s], w8 = w >> 8;
+      const f16x2 d0 = as_h2((w & 0x000f000fu) | 0x64006400u) + zc1;
+      const f16x2 d1 = __builtin_elementwise_fma(as_h2((w & 0x00f000f0u) | 0x64006400u),
+                                                 sixteenth, zc2);
+      const f16x2 d2 = as_h2((w8 & 0x000f000fu) | 0x64006400u) + zc1;
+      const f16x2 d3 = __builtin_elementwise_fma(as_h2((w8 & 0x00f000f0u) | 0x64006400u),
+                                                 sixteenth, zc2);
+      u32x4 bf;
+      bf[0] = as_u32(d0 * sc2);
+      bf[1] = as_u32(d1 * sc2);
+      bf[2] = as_u32(d2 * sc2);
+      bf[3] = as_u32(d3 * sc2);
+      return bf;
+    };
+    auto mma = [&](const u32x4 (&af)[4], const u32x4& bf) {
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+        acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[a]),
+                                                        __builtin_bit_cast(f16x8, bf), acc[a], 0,
+                                                        0, 0);
+    };
+    // fragments of slice s+1 are requested before the MFMAs of slice s are issued
+#define VLA_SB __builtin_amdgcn_sched_barrier(0)
+    u32x4 fa[4], fb[4];
+    read_a(0, fa);
+    u32x4 b0 = dequant(0);
+    VLA_SB;
+    read_a(1, fb);
+    VLA_SB;
+    mma(fa, b0);
+    u32x4 b1 = dequant(1);
+    VLA_SB;
+    read_a(2, fa);
+    VLA_SB;
+    mma(fb, b1);
+    b0 = dequant(2);
+    VLA_SB;
+    read_a(3, fb);
+    VLA_SB;
+    mma(fa, b0);
+    b1 = dequant(3);
+    VLA_SB;
+    mma(fb, b1);
+#undef VLA_SB
+    if (t + 1 < nsteps) store_x(buf ^ 1, xpark);
+    __syncthreads();
+  };
+
+  WStep w0, w1, w2, w3;
+  XSet xa, xb_;
+  load_x(0, xa);
+  load_x(1, xb_);
+  load_w(0, w0);
+  load_w(1, w1);
+  load_w(2, w2);
+  store_x(0, xa);
+  __syncthreads();
+
+  int t = 0;
+  for (; t + 4 <= nsteps; t += 4) {
+    k_step(t, w0, w3, xa, xb_);
+    k_step(t + 1, w1, w0, xb_, xa);
+    k_step(t + 2, w2, w1, xa, xb_);
+    k_step(t + 3, w3, w2, xb_, xa);
+  }
+  if (t < nsteps) k_step(t, w0, w3, xa, xb_);
+  if (t + 1 < nsteps) k_step(t + 1, w1, w0, xb_, xa);
+  if (t + 2 < nsteps) k_step(t + 2, w2, w1, xa, xb_);
+
+  // ---- epilogue: lane (h, c) holds column ncol, rows (i & 3) + 8 (i >> 2) + 4 h of each 32-row tile
+  if (!nok) return;
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int row = m0 + 32 * a + (i & 3) + 8 * (i >> 2) + 4 * h;
+      if (row >= m) continue;
+      if constexpr (SPLIT)
+        reinterpret_cast<float*>(outp)[((int64_t)blockIdx.z * m + row) * n + ncol] = acc[a][i];
+      else
+        reinterpret_cast<_Float16*>(outp)[(int64_t)row * n + ncol] = (_Float16)acc[a][i];
+    }
+}
+
 // out[i] = fp16(sum over splits of slab[s][i]); 4 elements per thread
 __global__ __launch_bounds__(256) void q4_splitk_reduce_kernel(const float* __restrict__ slabs,
                                                                _Float16* __restrict__ out,
@@ -239,19 +442,37 @@ __global__ __launch_bounds__(256) void awq_repack_zeros_kernel(const uint32_t* _
 
 using namespace vla;
 
-static int pick_splits(int m, int n, int k, int group) {
-  const int wgs = ((n + TN - 1) / TN) * ((m + TM - 1) / TM);
-  if (wgs >= 160) return 1;
-  int want = (256 + wgs - 1) / wgs;
+// The 32x32 kernel's launch shape: nw = waves (32 columns each) per workgroup, splits = K slices.
+// Measured on MI355X at M = 256: 256-column workgroups, and as many K slices (at most 8) as keep
+// the grid within one workgroup per CU -- a second round of workgroups costs more than the
+// emptier first one (N = 6144, K = 4096: 4 slices 31.6 us, 8 slices 39.8 us).
+// VLA_Q4_TUNE="nw,splits" overrides both (kernel studies).
+struct Q4Shape { int nw, splits; };
+
+static Q4Shape pick_shape(int m, int n, int k, int group) {
+  const int mt = (m + TM2 - 1) / TM2;
+  Q4Shape s;
+  s.nw = n > 128 ? 8 : 4;
+  const int wgs = ((n + 32 * s.nw - 1) / (32 * s.nw)) * mt;
+  int want = 256 / wgs;
   if (want > 8) want = 8;
+  if (want < 1) want = 1;
+  if (const char* e = getenv("VLA_Q4_TUNE")) {
+    int a = 0, b = 0;
+    if (sscanf(e, "%d,%d", &a, &b) == 2 && (a == 4 || a == 8) && b >= 1 && b <= 16) {
+      s.nw = a;
+      want = b;
+    }
+  }
   const int unit = group > TK ? group : TK;  // a split must hold whole groups and whole K steps
   while (want > 1 && (k % (want * unit)) != 0) --want;
-  return want;
+  s.splits = want;
+  return s;
 }
 
 extern "C" int64_t vla_q4_gemm_workspace_bytes(int m, int n, int k, int group) {
   if (m <= 0 || n <= 0 || k <= 0 || group <= 0) return 0;
-  const int s = pick_splits(m, n, k, group);
+  const int s = pick_shape(m, n, k, group).splits;
   return s > 1 ? (int64_t)s * m * n * 4 : 0;
 }
 
@@ -267,23 +488,35 @@ extern "C" int vla_q4_gemm_packed(const void* x, const int32_t* qweight, const i
   if (((uintptr_t)x % 16) || ((uintptr_t)out % 8)) return VLA_ERR_ARG;
   if (m == 0) return VLA_OK;
   hipStream_t s = (hipStream_t)stream;
-  int splits = pick_splits(m, n, k, group);
+  const bool m32 = group % TK == 0;                  // the 32x32 kernel wants whole K steps per group
+  Q4Shape shape = pick_shape(m, n, k, group);
+  int splits = shape.splits;
   if (splits > 1 && (!workspace || workspace_bytes < (int64_t)splits * m * n * 4 ||
                      ((uintptr_t)workspace % 16) || ((int64_t)m * n) % 4))
     splits = 1;
-  dim3 grid((n + TN - 1) / TN, (m + TM - 1) / TM, splits);
+  const int tn = m32 ? 32 * shape.nw : TN, tm = m32 ? TM2 : TM;
+  dim3 grid((n + tn - 1) / tn, (m + tm - 1) / tm, splits);
   const int kps = k / splits;
   void* dst = splits > 1 ? workspace : out;
-#define VLA_Q4_LAUNCH(Z, SP)                                                                     \
-  hipLaunchKernelGGL((q4_gemm_fast_kernel<Z, SP>), grid, dim3(kThreadsG), 0, s,                  \
-                     (const _Float16*)x, (const uint32_t*)qweight, (const uint32_t*)qzeros,      \
-                     (const _Float16*)scales, dst, m, n, k, group, kps)
+#define VLA_Q4_ARGS                                                                            \
+  (const _Float16*)x, (const uint32_t*)qweight, (const uint32_t*)qzeros, (const _Float16*)scales, \
+      dst, m, n, k, group, kps
+#define VLA_Q4_LAUNCH(Z, SP)                                                                   \
+  do {                                                                                         \
+    if (!m32)                                                                                  \
+      hipLaunchKernelGGL((q4_gemm_fast_kernel<Z, SP>), grid, dim3(kThreadsG), 0, s, VLA_Q4_ARGS); \
+    else if (shape.nw == 8)                                                                    \
+      hipLaunchKernelGGL((q4_gemm_m32_kernel<Z, SP, 8>), grid, dim3(512), 0, s, VLA_Q4_ARGS);  \
+    else                                                                                       \
+      hipLaunchKernelGGL((q4_gemm_m32_kernel<Z, SP, 4>), grid, dim3(256), 0, s, VLA_Q4_ARGS);  \
+  } while (0)
   if (zero_offset == 0) {
     if (splits > 1) VLA_Q4_LAUNCH(0, true); else VLA_Q4_LAUNCH(0, false);
   } else {
     if (splits > 1) VLA_Q4_LAUNCH(1, true); else VLA_Q4_LAUNCH(1, false);
   }
 #undef VLA_Q4_LAUNCH
+#undef VLA_Q4_ARGS
   VLA_HIP_CHECK(hipGetLastError());
   if (splits > 1) {
     const int64_t elems = (int64_t)m * n;
