@@ -202,6 +202,41 @@ int vla_rotary_embedding(const int64_t* positions, void* query, void* key,
 int vla_silu_and_mul(void* out, const void* input, int num_tokens, int d, int dtype,
                      void* stream);
 
+/* ---- fused forms (same results as the separate calls, fewer launches) ----------------------- */
+
+/* vla_q4_gemm_packed without its reduction launch: when the product was split along K,
+ * *num_slabs (> 1) fp32 slabs [num_slabs][m][n] are left in `workspace` for a consumer below to
+ * sum; *num_slabs == 0 means the result went straight to `out`.  The reference has no such
+ * split: its GEMMs (csrc/quantization/awq/gemm_kernels.cu:492-549, gptq/q_gemm.cu:1490-1541)
+ * always return the finished matrix. */
+int vla_q4_gemm_packed_partial(const void* x, const int32_t* qweight, const int32_t* qzeros,
+                               const void* scales, void* out, int m, int n, int k, int group,
+                               int zero_offset, void* workspace, int64_t workspace_bytes,
+                               int* num_slabs, void* stream);
+
+/* rotary_embedding (csrc/ops.h:38-40) on query/key in place, then reshape_and_cache
+ * (csrc/cache.h:15-25) of the rotated key and of value, in one launch -- the sequence every
+ * decoder layer runs between its qkv projection and attention
+ * (vllm/model_executor/models/llama.py:160-166, vllm/attention/ops/paged_attn.py:62-79).
+ * With `slabs` != NULL the input is read from the fp32 split-K slabs of the qkv projection
+ * ([num_slabs][num_tokens][slab_row], q/k/v starting at columns q_col/k_col/v_col), summed in
+ * slab order and rounded to the model dtype; query/key/value then receive the (rotated) result. */
+int vla_rotary_reshape_and_cache(const int64_t* positions, void* query, void* key, void* value,
+                                 const void* cos_sin_cache, void* key_cache, void* value_cache,
+                                 const int64_t* slot_mapping, int num_tokens, int num_heads,
+                                 int num_kv_heads, int head_size, int rot_dim, int64_t query_stride,
+                                 int64_t key_stride, int64_t value_stride, int block_size, int x,
+                                 int is_neox, int dtype, int kv_dtype, float kv_scale,
+                                 const float* slabs, int num_slabs, int64_t slab_stride,
+                                 int64_t slab_row, int q_col, int k_col, int v_col, void* stream);
+
+/* fused_add_rms_norm (csrc/ops.h:35-36) whose `input` arrives as split-K slabs
+ * [num_slabs][num_tokens][hidden_size] fp32: x = model_dtype(sum of slabs);
+ * residual = x + residual; out = rms_norm(residual) * weight. */
+int vla_fused_add_rms_norm_splitk(const float* slabs, int num_slabs, int64_t slab_stride, void* out,
+                                  void* residual, const void* weight, float epsilon,
+                                  int num_tokens, int hidden_size, int dtype, void* stream);
+
 /* Replaces get_max_shared_memory_per_block_device_attribute
  * (csrc/cuda_utils_kernels.cu:17-29). Returns bytes, or -1. */
 int vla_get_max_shared_memory_per_block(int device);

@@ -375,6 +375,96 @@ def q4_gemm_packed(x: torch.Tensor, qweight: torch.Tensor, qzeros: torch.Tensor,
     return out
 
 
+class SplitKSlabs:
+    """fp32 partial products [num_slabs, m, n] of an int4 GEMM whose K range was split, waiting
+    for a consumer (fused_add_rms_norm_splitk / rotary_reshape_and_cache) to sum them."""
+
+    def __init__(self, workspace: torch.Tensor, num_slabs: int, m: int, n: int):
+        self.workspace, self.num_slabs, self.m, self.n = workspace, num_slabs, m, n
+
+    def reduce(self, dtype=torch.float16) -> torch.Tensor:
+        """What the GEMM's own reduction launch computes (slab order, one rounding)."""
+        s = self.workspace[:self.num_slabs * self.m * self.n * 4].view(torch.float32)
+        s = s.view(self.num_slabs, self.m, self.n)
+        acc = s[0].clone()
+        for p in range(1, self.num_slabs):
+            acc += s[p]
+        return acc.to(dtype)
+
+
+def q4_gemm_packed_partial(x: torch.Tensor, qweight: torch.Tensor, qzeros: torch.Tensor,
+                           scales: torch.Tensor, zero_offset: int):
+    """q4_gemm_packed without the reduction launch.  Returns an [m, n] tensor when the product
+    was not split, else a SplitKSlabs."""
+    _require_cuda(x, qweight, qzeros, scales)
+    assert x.dtype == torch.float16 and scales.dtype == torch.float16
+    x = x.contiguous()
+    m, k = x.shape
+    n = qweight.shape[1]
+    group = k // qzeros.shape[0]
+    L = _lib.lib()
+    ws_bytes = L.vla_q4_gemm_workspace_bytes(m, n, k, group)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device) if ws_bytes else None
+    out = torch.empty((m, n), dtype=x.dtype, device=x.device) if not ws_bytes else None
+    ns = C.c_int(0)
+    with torch.cuda.device(x.device):
+        check(L.vla_q4_gemm_packed_partial(x.data_ptr(), qweight.data_ptr(), qzeros.data_ptr(),
+                                           scales.data_ptr(), _ptr(out) or _ptr(ws), m, n, k,
+                                           group, zero_offset, _ptr(ws), ws_bytes, C.byref(ns),
+                                           _stream(x.device)), "q4_gemm_packed_partial")
+    if ns.value > 1:
+        return SplitKSlabs(ws, ns.value, m, n)
+    return out
+
+
+def rotary_reshape_and_cache(positions: torch.Tensor, query: torch.Tensor, key: torch.Tensor,
+                             value: torch.Tensor, head_size: int, cos_sin_cache: torch.Tensor,
+                             is_neox: bool, key_cache, value_cache, slot_mapping: torch.Tensor,
+                             kv_cache_dtype: str, kv_scale: float,
+                             slabs: Optional[SplitKSlabs] = None) -> None:
+    """rotary_embedding(positions, query, key, ...) followed by reshape_and_cache(key, value, ...)
+    in one launch.  query [T, Hq*D], key/value [T, Hkv*D] may be strided row views of one qkv
+    tensor.  With `slabs` (the unreduced qkv projection, columns laid out q | k | v) the three
+    tensors are outputs only."""
+    _require_cuda(positions, query, key, value, cos_sin_cache, slot_mapping)
+    assert positions.dtype == torch.int64 and positions.is_contiguous()
+    assert slot_mapping.dtype == torch.int64 and slot_mapping.is_contiguous()
+    assert cos_sin_cache.dtype == query.dtype and cos_sin_cache.is_contiguous()
+    t = positions.numel()
+    q2, k2, v2 = query.view(t, -1), key.view(t, -1), value.view(t, -1)
+    assert q2.stride(1) == 1 and k2.stride(1) == 1 and v2.stride(1) == 1
+    hq, hkv = q2.shape[1] // head_size, k2.shape[1] // head_size
+    sp, ns, sstride, srow = None, 0, 0, 0
+    if slabs is not None:
+        assert slabs.m == t and slabs.n == (hq + 2 * hkv) * head_size
+        sp, ns, sstride, srow = slabs.workspace.data_ptr(), slabs.num_slabs, slabs.m * slabs.n, slabs.n
+    with torch.cuda.device(query.device):
+        check(_lib.lib().vla_rotary_reshape_and_cache(
+            positions.data_ptr(), query.data_ptr(), key.data_ptr(), value.data_ptr(),
+            cos_sin_cache.data_ptr(), key_cache.data_ptr(), value_cache.data_ptr(),
+            slot_mapping.data_ptr(), t, hq, hkv, head_size, cos_sin_cache.shape[1], q2.stride(0),
+            k2.stride(0), v2.stride(0), key_cache.size(3), key_cache.size(4),
+            1 if is_neox else 0, _dt(query), _lib.kv_dtype_code(kv_cache_dtype), kv_scale, sp, ns,
+            sstride, srow, 0, hq * head_size, (hq + hkv) * head_size, _stream(query.device)),
+            "rotary_reshape_and_cache")
+
+
+def fused_add_rms_norm_splitk(slabs: SplitKSlabs, out: torch.Tensor, residual: torch.Tensor,
+                              weight: torch.Tensor, epsilon: float) -> None:
+    """fused_add_rms_norm whose input is the unreduced product `slabs`: residual += sum(slabs)
+    (rounded to the model dtype first), out = rms_norm(residual) * weight."""
+    _require_cuda(out, residual, weight)
+    assert out.is_contiguous() and residual.is_contiguous() and weight.is_contiguous()
+    h = residual.shape[-1]
+    t = residual.numel() // h
+    assert slabs.m == t and slabs.n == h and out.shape == residual.shape
+    with torch.cuda.device(out.device):
+        check(_lib.lib().vla_fused_add_rms_norm_splitk(
+            slabs.workspace.data_ptr(), slabs.num_slabs, slabs.m * slabs.n, out.data_ptr(),
+            residual.data_ptr(), weight.data_ptr(), epsilon, t, h, _dt(out), _stream(out.device)),
+            "fused_add_rms_norm_splitk")
+
+
 def gptq_gemm(a: torch.Tensor, b_q_weight: torch.Tensor, b_gptq_qzeros: torch.Tensor,
               b_gptq_scales: torch.Tensor, b_g_idx: torch.Tensor, use_exllama: bool,
               bit: int) -> torch.Tensor:

@@ -123,8 +123,9 @@ class Gfx950PagedAttentionImpl(AttentionImpl):
 
     def forward(self, query: torch.Tensor, key: torch.Tensor, value: torch.Tensor,
                 kv_cache: Optional[torch.Tensor], attn_metadata: Gfx950PagedAttentionMetadata,
-                kv_scale: float = 1.0) -> torch.Tensor:
-        """query [T, Hq*D], key/value [T, Hkv*D], kv_cache [2, NB, BS*Hkv*D] or None -> [T, Hq*D]."""
+                kv_scale: float = 1.0, kv_cached: bool = False) -> torch.Tensor:
+        """query [T, Hq*D], key/value [T, Hkv*D], kv_cache [2, NB, BS*Hkv*D] or None -> [T, Hq*D].
+        kv_cached: this step's key/value were already written to the cache by the caller."""
         num_tokens, hidden = query.shape
         query = query.view(-1, self.num_heads, self.head_size)
         key = key.view(-1, self.num_kv_heads, self.head_size)
@@ -134,9 +135,10 @@ class Gfx950PagedAttentionImpl(AttentionImpl):
         if kv_cache is not None:
             key_cache, value_cache = PagedAttention.split_kv_cache(kv_cache, self.num_kv_heads,
                                                                    self.head_size)
-            PagedAttention.write_to_paged_cache(key, value, key_cache, value_cache,
-                                                attn_metadata.slot_mapping, self.kv_cache_dtype,
-                                                kv_scale)
+            if not kv_cached:
+                PagedAttention.write_to_paged_cache(key, value, key_cache, value_cache,
+                                                    attn_metadata.slot_mapping,
+                                                    self.kv_cache_dtype, kv_scale)
 
         n_pre, n_dec = attn_metadata.num_prefill_tokens, attn_metadata.num_decode_tokens
         assert key.shape[0] == n_pre + n_dec and value.shape[0] == n_pre + n_dec

@@ -29,7 +29,13 @@ class Attention(nn.Module):
                                            sliding_window, kv_cache_dtype, blocksparse_params)
 
     def forward(self, query: torch.Tensor, key: torch.Tensor, value: torch.Tensor,
-                kv_cache: Optional[torch.Tensor], attn_metadata: AttentionMetadata) -> torch.Tensor:
+                kv_cache: Optional[torch.Tensor], attn_metadata: AttentionMetadata,
+                kv_cached: bool = False) -> torch.Tensor:
+        """kv_cached: key/value of this step are already in the cache (the caller used the fused
+        rotary + cache-write kernel), so the backend must not write them again."""
+        if kv_cached:
+            return self.impl.forward(query, key, value, kv_cache, attn_metadata, self._kv_scale,
+                                     kv_cached=True)
         return self.impl.forward(query, key, value, kv_cache, attn_metadata, self._kv_scale)
 
     def extra_repr(self) -> str:

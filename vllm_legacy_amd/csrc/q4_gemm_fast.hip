@@ -476,11 +476,14 @@ extern "C" int64_t vla_q4_gemm_workspace_bytes(int m, int n, int k, int group) {
   return s > 1 ? (int64_t)s * m * n * 4 : 0;
 }
 
-extern "C" int vla_q4_gemm_packed(const void* x, const int32_t* qweight, const int32_t* qzeros,
-                                  const void* scales, void* out, int m, int n, int k, int group,
-                                  int zero_offset, void* workspace, int64_t workspace_bytes,
-                                  void* stream) {
+// reduce: sum the split-K slabs into `out` here; otherwise leave them in the workspace and report
+// their number (0: the product went straight to `out`) for a consumer that sums them itself
+static int q4_gemm_run(const void* x, const int32_t* qweight, const int32_t* qzeros,
+                       const void* scales, void* out, int m, int n, int k, int group,
+                       int zero_offset, void* workspace, int64_t workspace_bytes, void* stream,
+                       bool reduce, int* num_slabs) {
   (void)hipGetLastError();
+  if (num_slabs) *num_slabs = 0;
   if (!x || !qweight || !qzeros || !scales || !out || m < 0) return VLA_ERR_ARG;
   if (n % 8 || k % TK || group <= 0 || group % 32 || k % group ||
       (zero_offset != 0 && zero_offset != 1))
@@ -518,13 +521,33 @@ extern "C" int vla_q4_gemm_packed(const void* x, const int32_t* qweight, const i
 #undef VLA_Q4_LAUNCH
 #undef VLA_Q4_ARGS
   VLA_HIP_CHECK(hipGetLastError());
-  if (splits > 1) {
+  if (splits > 1 && reduce) {
     const int64_t elems = (int64_t)m * n;
     hipLaunchKernelGGL(q4_splitk_reduce_kernel, dim3((unsigned)((elems / 4 + 255) / 256)),
                        dim3(256), 0, s, (const float*)workspace, (_Float16*)out, elems, splits);
     VLA_HIP_CHECK(hipGetLastError());
+  } else if (splits > 1 && num_slabs) {
+    *num_slabs = splits;
   }
   return VLA_OK;
+}
+
+extern "C" int vla_q4_gemm_packed(const void* x, const int32_t* qweight, const int32_t* qzeros,
+                                  const void* scales, void* out, int m, int n, int k, int group,
+                                  int zero_offset, void* workspace, int64_t workspace_bytes,
+                                  void* stream) {
+  return q4_gemm_run(x, qweight, qzeros, scales, out, m, n, k, group, zero_offset, workspace,
+                     workspace_bytes, stream, true, nullptr);
+}
+
+extern "C" int vla_q4_gemm_packed_partial(const void* x, const int32_t* qweight,
+                                          const int32_t* qzeros, const void* scales, void* out,
+                                          int m, int n, int k, int group, int zero_offset,
+                                          void* workspace, int64_t workspace_bytes,
+                                          int* num_slabs, void* stream) {
+  if (!num_slabs) return VLA_ERR_ARG;
+  return q4_gemm_run(x, qweight, qzeros, scales, out, m, n, k, group, zero_offset, workspace,
+                     workspace_bytes, stream, false, num_slabs);
 }
 
 extern "C" int vla_awq_repack(const int32_t* qweight, const int32_t* qzeros, int32_t* out_qweight,

@@ -21,8 +21,8 @@ from .parallel_state import (get_tensor_model_parallel_cpu_group,
 
 def tensor_model_parallel_all_reduce(input_: torch.Tensor) -> torch.Tensor:
     """SUM over the TP group, in place; returns its argument."""
-    if get_tensor_model_parallel_world_size() == 1:
-        return input_
+    if get_tensor_model_parallel_world_size() == 1 or not isinstance(input_, torch.Tensor):
+        return input_                     # single rank (possibly unreduced split-K slabs)
     dist.all_reduce(input_, group=get_tensor_model_parallel_group())
     return input_
 

@@ -22,8 +22,15 @@ class RMSNorm(nn.Module):
                                    requires_grad=False)
         self.variance_epsilon = eps
 
-    def forward(self, x: torch.Tensor, residual: Optional[torch.Tensor] = None
+    def forward(self, x, residual: Optional[torch.Tensor] = None
                 ) -> Union[torch.Tensor, Tuple[torch.Tensor, torch.Tensor]]:
+        if isinstance(x, ops.SplitKSlabs):
+            # the producing GEMM left its split-K partial sums for this kernel to add up
+            assert residual is not None
+            out = torch.empty_like(residual)
+            ops.fused_add_rms_norm_splitk(x, out, residual, self.weight.data,
+                                          self.variance_epsilon)
+            return out, residual
         if residual is not None:
             ops.fused_add_rms_norm(x, residual, self.weight.data, self.variance_epsilon)
             return x, residual

@@ -16,7 +16,9 @@ from typing import List, Optional
 import torch
 import torch.nn as nn
 
+from vllm_legacy_amd import _custom_ops as ops
 from vllm_legacy_amd.attention.layer import Attention
+from vllm_legacy_amd.attention.ops.paged_attn import PagedAttention
 from vllm_legacy_amd.distributed.communication_op import (tensor_model_parallel_all_reduce,
                                                           tensor_model_parallel_gather)
 from vllm_legacy_amd.distributed.parallel_state import (get_tensor_model_parallel_rank,
@@ -86,9 +88,13 @@ class QuantLinear(nn.Module):
         s.uniform_(0.5, 1.5, generator=generator)
         self.scales.data = (s * (1e-2 * (4096.0 / in_features)**0.5)).to(dtype)
 
-    def forward(self, x: torch.Tensor) -> torch.Tensor:
+    def forward(self, x: torch.Tensor, defer_reduce: bool = False):
+        """defer_reduce: the caller feeds the result to a kernel that can sum split-K slabs
+        itself, so an ops.SplitKSlabs may come back instead of a tensor."""
         if self.method is None:
             return torch.matmul(x, self.weight)
+        if defer_reduce and hasattr(self.method, "apply_partial"):
+            return self.method.apply_partial(self, x)
         return self.method.apply(self, x)
 
 
@@ -97,7 +103,7 @@ class LlamaDecodeLayer(nn.Module):
     def __init__(self, cfg: LlamaConfig, quant: str, kv_cache_dtype: str, tp: int, device,
                  generator, dtype):
         super().__init__()
-        self.cfg = cfg
+        self.cfg, self.tp = cfg, tp
         self.hq = cfg.num_attention_heads // tp
         self.hkv = max(1, cfg.num_key_value_heads // tp)   # replicated when tp > kv heads (llama.py:112-116)
         d = cfg.head_dim
@@ -116,20 +122,37 @@ class LlamaDecodeLayer(nn.Module):
                               dtype=dtype)
 
     def forward(self, positions, hidden, residual, kv_cache, attn_metadata, rotary_emb):
-        # layer order of vllm/model_executor/models/llama.py:196-224
+        """Layer order of vllm/model_executor/models/llama.py:196-224.  `hidden` may arrive as the
+        previous layer's unreduced down projection (ops.SplitKSlabs); fused kernels are used
+        where they compute the same values from fewer launches: split-K sums folded into the
+        following add + RMSNorm or rotary step, rotary embedding and the cache write in one."""
         if residual is None:
             residual = hidden
             hidden = self.input_layernorm(hidden)
         else:
             hidden, residual = self.input_layernorm(hidden, residual)
-        qkv = self.qkv_proj(hidden)
+        decode_only = kv_cache is not None and attn_metadata.num_prefill_tokens == 0
+        qkv = self.qkv_proj(hidden, defer_reduce=decode_only)
+        slabs = qkv if isinstance(qkv, ops.SplitKSlabs) else None
+        if slabs is not None:
+            qkv = torch.empty((slabs.m, slabs.n), dtype=hidden.dtype, device=hidden.device)
         q, k, v = qkv.split([self.q_size, self.kv_size, self.kv_size], dim=-1)
-        rotary_emb(positions, q, k)     # in place on the strided views of qkv
-        attn_out = self.attn(q, k, v, kv_cache, attn_metadata)
-        hidden = tensor_model_parallel_all_reduce(self.o_proj(attn_out))
+        if decode_only:
+            key_cache, value_cache = PagedAttention.split_kv_cache(kv_cache, self.hkv,
+                                                                   self.cfg.head_dim)
+            ops.rotary_reshape_and_cache(positions, q, k, v, self.cfg.head_dim,
+                                         rotary_emb.cos_sin_cache, rotary_emb.is_neox_style,
+                                         key_cache, value_cache, attn_metadata.slot_mapping,
+                                         self.attn.kv_cache_dtype, self.attn._kv_scale, slabs)
+            attn_out = self.attn(q, k, v, kv_cache, attn_metadata, kv_cached=True)
+        else:
+            rotary_emb(positions, q, k)     # in place on the strided views of qkv
+            attn_out = self.attn(q, k, v, kv_cache, attn_metadata)
+        fuse = self.tp == 1                 # with TP the partial sums must be all-reduced first
+        hidden = tensor_model_parallel_all_reduce(self.o_proj(attn_out, defer_reduce=fuse))
         hidden, residual = self.post_attention_layernorm(hidden, residual)
         hidden = tensor_model_parallel_all_reduce(
-            self.down_proj(self.act_fn(self.gate_up_proj(hidden))))
+            self.down_proj(self.act_fn(self.gate_up_proj(hidden)), defer_reduce=fuse))
         return hidden, residual
 
 

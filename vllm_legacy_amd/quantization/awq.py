@@ -65,6 +65,17 @@ class AWQLinearMethod:
                                                          dtype=params_dtype, device=device),
                                              requires_grad=False))
 
+    def apply_partial(self, layer: torch.nn.Module, x: torch.Tensor):
+        """apply() that may return the unreduced split-K slabs (ops.SplitKSlabs) for a fused
+        consumer instead of the finished [tokens, out] matrix.  2-D input, no bias."""
+        if x.dim() != 2 or x.shape[1] % 64 != 0:
+            return self.apply(layer, x)
+        packed = getattr(layer, "_k_packed", None)
+        if packed is None:
+            packed = ops.awq_repack(layer.qweight, layer.qzeros)
+            layer._k_packed = packed
+        return ops.q4_gemm_packed_partial(x, packed[0], packed[1], layer.scales, 0)
+
     def apply(self, layer: torch.nn.Module, x: torch.Tensor,
               bias: Optional[torch.Tensor] = None) -> torch.Tensor:
         qweight, scales, qzeros = layer.qweight, layer.scales, layer.qzeros
