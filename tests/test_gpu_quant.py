@@ -209,3 +209,38 @@ def test_awq_linear_method_uses_packed_path(ops):
     torch.cuda.synchronize()
     assert out.shape == (3, 11, oc) and hasattr(layer, "_k_packed")
     _gemm_close(out.reshape(m, oc), O.gemm_f16(x.reshape(m, ic), O.awq_dequantize(qw, sc, qz)))
+
+
+# Per-GPU layer shapes of the other target configurations: Llama-3-70B GPTQ at TP=8
+# (qkv 8192->1280, o 1024->8192, gate_up 8192->7168, down 3584->8192) through the GPTQ linear
+# method's exllama path, and Mixtral-8x7B AWQ experts at TP=2 (w1/w3 4096->7168, w2 7168->4096).
+@pytest.mark.parametrize("k,n", [(8192, 1280), (1024, 8192), (8192, 7168), (3584, 8192)])
+def test_gptq_linear_method_llama70b_tp8_shapes(ops, k, n):
+    from vllm_legacy_amd.quantization.gptq import GPTQConfig, GPTQLinearMethod
+    rng = np.random.default_rng(k + n)
+    m, group = 48, 128
+    qw, qz, sc = _gptq_weights(rng, k, n, group)
+    layer = torch.nn.Module()
+    meth = GPTQLinearMethod(GPTQConfig(4, group, False))
+    meth.create_weights(layer, k, [n], k, n, torch.float16, device="cuda")
+    layer.qweight.data, layer.qzeros.data, layer.scales.data = _cuda(qw.copy()), _cuda(qz), _cuda(sc, O.DT_F16)
+    x = O.to_bits(rng.uniform(-1, 1, (m, k)).astype(np.float32), O.DT_F16)
+    out = meth.apply(layer, _cuda(x, O.DT_F16))
+    torch.cuda.synchronize()
+    want = O.gemm_f16(x, O.gptq_dequantize(qw, qz, sc))
+    np.testing.assert_allclose(out.float().cpu().numpy(), O.from_bits(want, O.DT_F16), rtol=3e-3,
+                               atol=8e-3)
+
+
+@pytest.mark.parametrize("k,n", [(4096, 7168), (7168, 4096)])
+def test_awq_packed_gemm_mixtral_tp2_expert_shapes(ops, k, n):
+    rng = np.random.default_rng(k)
+    m, group = 40, 128
+    qw, qz, sc = _awq_weights(rng, k, n, group)
+    x = O.to_bits(rng.uniform(-1, 1, (m, k)).astype(np.float32), O.DT_F16)
+    pw, pz = ops.awq_repack(_cuda(qw), _cuda(qz))
+    got = ops.q4_gemm_packed(_cuda(x, O.DT_F16), pw, pz, _cuda(sc, O.DT_F16), 0)
+    torch.cuda.synchronize()
+    want = O.gemm_f16(x, O.awq_dequantize(qw, sc, qz))
+    np.testing.assert_allclose(got.float().cpu().numpy(), O.from_bits(want, O.DT_F16), rtol=3e-3,
+                               atol=8e-3)
