@@ -139,13 +139,23 @@ def cpu_baseline(args):
 
 def main():
     args = parse()
+    if os.environ.get("VLA_BENCH_WATCHDOG"):
+        # debugging aid: dump every thread's stack and exit if the run is still going after N s
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["VLA_BENCH_WATCHDOG"]), exit=True)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # VLA_BENCH_REHEARSAL=1: run the tensor-parallel code path with every rank on GPU 0 and Gloo
+    # collectives (a one-GPU box cannot host an RCCL group); numbers from it mean nothing.
+    rehearsal = os.environ.get("VLA_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         from vllm_legacy_amd.distributed import parallel_state as ps
-        ps.init_distributed_environment(local_rank=local_rank, backend="nccl")
+        ps.init_distributed_environment(local_rank=local_rank,
+                                        backend="gloo" if rehearsal else "nccl")
         ps.initialize_model_parallel(world)
     assert world == args.gpus or world == 1, "launch with torch.distributed.run for --gpus > 1"
     torch.cuda.set_device(local_rank)
@@ -191,11 +201,11 @@ def main():
 
     # ---- optional graph capture (decode is replayed from a graph in the reference too,
     # vllm/worker/model_runner.py:512-515)
-    use_graph = not args.no_graph
+    use_graph = not args.no_graph and not rehearsal
     graph = None
     stream = torch.cuda.Stream(device=device)
     with torch.cuda.stream(stream):
-        step()  # first call: lazy inits (e.g. the GPTQ shuffle)
+        step()  # first call: lazy inits (the AWQ repack, the GPTQ shuffle)
         torch.cuda.synchronize()
         if use_graph:
             try:
@@ -204,12 +214,18 @@ def main():
                     step()
             except Exception as e:  # e.g. a collective that cannot be captured
                 if rank == 0:
-                    print(f"[bench] graph capture failed ({type(e).__name__}: {e}); running eagerly",
-                          file=sys.stderr)
+                    print(f"[bench] graph capture failed ({type(e).__name__}: "
+                          f"{str(e).splitlines()[0]}); running eagerly", file=sys.stderr)
                 graph = None
-                torch.cuda.synchronize()
+    if use_graph and graph is None:
+        # a failed capture leaves its stream unusable: drain the device and move to a fresh one
+        try:
+            torch.cuda.synchronize()
+        except Exception:
+            pass
+        stream = torch.cuda.Stream(device=device)
+    with torch.cuda.stream(stream):
         run = graph.replay if graph is not None else step
-
         for _ in range(args.warmup):
             run()
         torch.cuda.synchronize()

@@ -23,7 +23,15 @@ def tensor_model_parallel_all_reduce(input_: torch.Tensor) -> torch.Tensor:
     """SUM over the TP group, in place; returns its argument."""
     if get_tensor_model_parallel_world_size() == 1 or not isinstance(input_, torch.Tensor):
         return input_                     # single rank (possibly unreduced split-K slabs)
-    dist.all_reduce(input_, group=get_tensor_model_parallel_group())
+    group = get_tensor_model_parallel_group()
+    if input_.is_cuda and dist.get_backend(group) == "gloo":
+        # rehearsal of the GPU code path without RCCL (several ranks on one GPU): stage
+        # through the host, where Gloo is at home
+        host = input_.cpu()
+        dist.all_reduce(host, group=group)
+        input_.copy_(host)
+        return input_
+    dist.all_reduce(input_, group=group)
     return input_
 
 
@@ -51,10 +59,13 @@ def tensor_model_parallel_gather(input_: torch.Tensor, dst: int = 0, dim: int = 
     if dim < 0:
         dim += input_.dim()
     me = get_tensor_model_parallel_rank()
-    bufs = [torch.empty_like(input_) for _ in range(world)] if me == dst else None
-    dist.gather(input_.contiguous(), bufs, dst=get_tensor_model_parallel_src_rank() + dst,
-                group=get_tensor_model_parallel_group())
-    return torch.cat(bufs, dim=dim) if me == dst else None
+    group = get_tensor_model_parallel_group()
+    src = input_.contiguous()
+    if src.is_cuda and dist.get_backend(group) == "gloo":
+        src = src.cpu()                   # rehearsal without RCCL, see all-reduce above
+    bufs = [torch.empty_like(src) for _ in range(world)] if me == dst else None
+    dist.gather(src, bufs, dst=get_tensor_model_parallel_src_rank() + dst, group=group)
+    return torch.cat(bufs, dim=dim).to(input_.device) if me == dst else None
 
 
 def broadcast_tensor_dict(tensor_dict: Optional[Dict[str, Any]] = None, src: int = 0) -> Dict[str, Any]:
