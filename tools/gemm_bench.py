@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--sets", type=int, default=8)
     ap.add_argument("--check", action="store_true")
     ap.add_argument("--only", default="")
+    ap.add_argument("--tp", type=int, default=1, help="per-GPU shapes at this tensor-parallel degree")
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
     g = torch.Generator(device=dev).manual_seed(0)
@@ -34,6 +35,10 @@ def main():
     for name, (k, n) in SHAPES.items():
         if a.only and name != a.only:
             continue
+        if name in ("qkv", "gate_up"):
+            n //= a.tp                    # column-parallel
+        else:
+            k //= a.tp                    # row-parallel
         sets = []
         for _ in range(a.sets):
             qw = torch.randint(-2**31, 2**31 - 1, (k, n // 8), dtype=torch.int64, device=dev,
@@ -56,16 +61,26 @@ def main():
         for i in range(3):
             ops.q4_gemm_packed(x, *sets[i % a.sets][3:], sets[i % a.sets][2], 0)
         torch.cuda.synchronize()
-        evs = []
-        for i in range(a.iters):
-            _, _, sc, pw, pz = sets[i % a.sets]
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            ops.q4_gemm_packed(x, pw, pz, sc, 0)
-            e1.record()
-            evs.append((e0, e1))
-        torch.cuda.synchronize()
-        ts = sorted(e0.elapsed_time(e1) for e0, e1 in evs)
+        # the calls are replayed from a graph so that host launch cost (two launches and a torch
+        # allocation per call) does not hide the kernels' time
+        stream = torch.cuda.Stream()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(stream):
+            with torch.cuda.graph(graph, stream=stream):
+                for i in range(a.iters):
+                    _, _, sc, pw, pz = sets[i % a.sets]
+                    ops.q4_gemm_packed(x, pw, pz, sc, 0)
+            graph.replay()
+            torch.cuda.synchronize()
+            ts = []
+            for _ in range(5):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(stream)
+                graph.replay()
+                e1.record(stream)
+                torch.cuda.synchronize()
+                ts.append(e0.elapsed_time(e1) / a.iters)
+        ts.sort()
         med = ts[len(ts) // 2]
         res[name] = {"k": k, "n": n, "us_median": round(med * 1e3, 1), "us_min": round(ts[0] * 1e3, 1),
                      "TFLOPs": round(2 * a.m * k * n / (med * 1e-3) / 1e12, 1)}

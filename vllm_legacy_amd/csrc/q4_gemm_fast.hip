@@ -443,19 +443,25 @@ __global__ __launch_bounds__(256) void awq_repack_zeros_kernel(const uint32_t* _
 using namespace vla;
 
 // The 32x32 kernel's launch shape: nw = waves (32 columns each) per workgroup, splits = K slices.
-// Measured on MI355X at M = 256: 256-column workgroups, and as many K slices (at most 8) as keep
-// the grid within one workgroup per CU -- a second round of workgroups costs more than the
-// emptier first one (N = 6144, K = 4096: 4 slices 31.6 us, 8 slices 39.8 us).
+// From sweeps on MI355X at M = 256 over the Llama-3-8B layer shapes at TP 1/2/4/8:
+//  * 256-column workgroups for wide, deep layers; 128-column ones (two fit a CU) when the layer is
+//    narrow (N < 3072) or shallow (K <= 2048);
+//  * as many K slices (at most 8) as keep the grid within one workgroup per CU -- a second round
+//    of workgroups costs more than the emptier first one (N = 6144, K = 4096: 4 slices 31.6 us,
+//    8 slices 39.8 us) -- but never slices shorter than 8 K steps: below that the fixed cost of
+//    the slabs and their reduction exceeds what the shorter loop saves (K = 1024, N = 4096:
+//    1 slice 15.3 us, 4 slices 19.2 us).
 // VLA_Q4_TUNE="nw,splits" overrides both (kernel studies).
 struct Q4Shape { int nw, splits; };
 
 static Q4Shape pick_shape(int m, int n, int k, int group) {
   const int mt = (m + TM2 - 1) / TM2;
   Q4Shape s;
-  s.nw = n > 128 ? 8 : 4;
+  s.nw = (n < 3072 || k <= 2048) ? 4 : 8;
   const int wgs = ((n + 32 * s.nw - 1) / (32 * s.nw)) * mt;
   int want = 256 / wgs;
   if (want > 8) want = 8;
+  if (want > k / (8 * TK)) want = k / (8 * TK);
   if (want < 1) want = 1;
   if (const char* e = getenv("VLA_Q4_TUNE")) {
     int a = 0, b = 0;
