@@ -230,3 +230,24 @@ def test_against_reference_cpu_kernel_fixtures(ops, golden_dir, name):
     torch.cuda.synchronize()
     assert np.array_equal(T.bits(kc), z["key_cache_copied"])
     assert np.array_equal(T.bits(vc), z["value_cache_copied"])
+
+
+@pytest.mark.parametrize("direction", [("cuda", "cpu"), ("cpu", "cuda")])
+def test_swap_blocks_scattered_pageable_host(ops, direction):
+    """Host memory that is not pinned cannot be addressed by the copy kernel: the per-run copy
+    path must give the same bytes."""
+    rng = np.random.default_rng(9)
+    random.seed(1)
+    NB, M = 256, 64
+    src = rng.integers(0, 255, (NB, 4096)).astype(np.uint8)
+    dst = rng.integers(0, 255, (NB, 4096)).astype(np.uint8)
+    mapping = np.array(list(zip(random.sample(range(NB), M), random.sample(range(NB), M))), dtype=np.int64)
+    ts = torch.from_numpy(src.copy())
+    td = torch.from_numpy(dst.copy())
+    ts = ts.cuda() if direction[0] == "cuda" else ts
+    td = td.cuda() if direction[1] == "cuda" else td
+    ops.swap_blocks(ts, td, torch.from_numpy(mapping))
+    torch.cuda.synchronize()
+    want = dst.copy()
+    O.swap_blocks(src, want, mapping)
+    assert np.array_equal(td.cpu().numpy(), want)

@@ -127,7 +127,66 @@ __global__ __launch_bounds__(256) void copy_blocks_kernel(CopyPtrs ptrs,
   for (int64_t i = threadIdx.x; i < vecs_per_block; i += blockDim.x) d[i] = s[i];
 }
 
+// ------------------------------------------------------------------ swap_blocks (scattered)
+// Many short copies: one launch moves up to kSwapPairs blocks, the pair list riding in the kernel
+// arguments.  Used when the mapping does not collapse into a few long runs and both sides are
+// device-addressable (device memory, or pinned host memory through its device alias).
+constexpr int kSwapPairs = 120;
+struct SwapPairs {
+  int64_t src[kSwapPairs];
+  int64_t dst[kSwapPairs];
+};
+
+__global__ __launch_bounds__(256) void swap_blocks_kernel(const char* __restrict__ src,
+                                                          char* __restrict__ dst, SwapPairs p,
+                                                          int64_t block_bytes) {
+  const u32x4* s = reinterpret_cast<const u32x4*>(src + p.src[blockIdx.x] * block_bytes);
+  u32x4* d = reinterpret_cast<u32x4*>(dst + p.dst[blockIdx.x] * block_bytes);
+  const int64_t vecs = block_bytes / 16;
+  for (int64_t i = (int64_t)blockIdx.y * blockDim.x + threadIdx.x; i < vecs;
+       i += (int64_t)gridDim.y * blockDim.x)
+    d[i] = s[i];
+}
+
 // ------------------------------------------------------------------ convert_fp8
+// eight elements per lane: 16-byte accesses on the 16-bit side, 8-byte on the fp8 side
+template <class S, bool TO_FP8>
+__global__ __launch_bounds__(256) void convert_fp8_vec8_kernel(void* __restrict__ dst,
+                                                               const void* __restrict__ src,
+                                                               int64_t n8, float scale) {
+  using T = typename S::T;
+  static_assert(sizeof(T) == 2, "16-bit model dtypes only");
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += stride) {
+    if constexpr (TO_FP8) {
+      const u32x4 v = reinterpret_cast<const u32x4*>(src)[i];
+      u32x2 o = {0, 0};
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const T el = __builtin_bit_cast(T, (uint16_t)(v[e >> 1] >> (16 * (e & 1))));
+        o[e >> 2] |= (uint32_t)fp8_e4m3_encode(S::to_f32(el) / scale) << (8 * (e & 3));
+      }
+      reinterpret_cast<u32x2*>(dst)[i] = o;
+    } else {
+      const u32x2 v = reinterpret_cast<const u32x2*>(src)[i];
+      u32x4 o;
+#pragma unroll
+      for (int e = 0; e < 8; e += 2) {
+        uint32_t w = 0;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const uint8_t b = (uint8_t)(v[(e + h) >> 2] >> (8 * ((e + h) & 3)));
+          T r = S::from_f32(fp8_e4m3_decode(b) * scale);
+          if (b == 0x80) r = S::from_f32(-0.0f);   // see the scalar kernel below
+          w |= (uint32_t)__builtin_bit_cast(uint16_t, r) << (16 * h);
+        }
+        o[e >> 1] = w;
+      }
+      reinterpret_cast<u32x4*>(dst)[i] = o;
+    }
+  }
+}
+
 template <class S, bool TO_FP8>
 __global__ __launch_bounds__(256) void convert_fp8_kernel(void* __restrict__ dst,
                                                           const void* __restrict__ src, int64_t n,
@@ -152,6 +211,21 @@ __global__ __launch_bounds__(256) void convert_fp8_kernel(void* __restrict__ dst
 template <class S>
 int launch_convert(void* dst, const void* src, int64_t n, float scale, int to_fp8, hipStream_t s) {
   if (n == 0) return VLA_OK;
+  if constexpr (sizeof(typename S::T) == 2) {
+    if (n % 8 == 0 && ((uintptr_t)dst % 16 == 0) && ((uintptr_t)src % 16 == 0)) {
+      const int64_t n8 = n / 8;
+      int64_t vb = (n8 + 255) / 256;
+      if (vb > 16384) vb = 16384;
+      if (to_fp8)
+        hipLaunchKernelGGL((convert_fp8_vec8_kernel<S, true>), dim3((unsigned)vb), dim3(256), 0, s,
+                           dst, src, n8, scale);
+      else
+        hipLaunchKernelGGL((convert_fp8_vec8_kernel<S, false>), dim3((unsigned)vb), dim3(256), 0, s,
+                           dst, src, n8, scale);
+      VLA_HIP_CHECK(hipGetLastError());
+      return VLA_OK;
+    }
+  }
   int64_t blocks = (n + 255) / 256;
   if (blocks > 8192) blocks = 8192;
   if (to_fp8)
@@ -245,10 +319,54 @@ extern "C" int vla_swap_blocks(const void* src, void* dst, const int64_t* block_
   hipStream_t s = (hipStream_t)stream;
   const char* sp = static_cast<const char*>(src);
   char* dp = static_cast<char*>(dst);
+  int runs = 0;
+  for (int i = 0; i < num_pairs; ++i) {
+    if (block_mapping[2 * i] < 0 || block_mapping[2 * i + 1] < 0) return VLA_ERR_ARG;
+    if (i == 0 || block_mapping[2 * i] != block_mapping[2 * i - 2] + 1 ||
+        block_mapping[2 * i + 1] != block_mapping[2 * i - 1] + 1)
+      ++runs;
+  }
+  // A scattered mapping is moved by one kernel per 120 blocks instead of one copy call per block,
+  // if the host side (when there is one) is pinned memory the device can address.
+  if (runs > 4 && block_bytes % 16 == 0) {
+    const char* ksrc = sp;
+    char* kdst = dp;
+    bool ok = true;
+    auto device_alias = [&](const void* host) -> void* {
+      hipPointerAttribute_t at;
+      if (hipPointerGetAttributes(&at, host) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+      }
+      return at.type == hipMemoryTypeHost ? at.devicePointer : nullptr;
+    };
+    if (direction == VLA_SWAP_D2H) {
+      kdst = static_cast<char*>(device_alias(dst));
+      ok = kdst != nullptr;
+    } else if (direction == VLA_SWAP_H2D) {
+      ksrc = static_cast<const char*>(device_alias(src));
+      ok = ksrc != nullptr;
+    }
+    if (ok && ((uintptr_t)ksrc % 16 == 0) && ((uintptr_t)kdst % 16 == 0)) {
+      int64_t ysplit = (block_bytes / 16 + 256 * 4 - 1) / (256 * 4);
+      if (ysplit > 64) ysplit = 64;
+      for (int i0 = 0; i0 < num_pairs; i0 += kSwapPairs) {
+        const int np = min(kSwapPairs, num_pairs - i0);
+        SwapPairs p;
+        for (int j = 0; j < np; ++j) {
+          p.src[j] = block_mapping[2 * (i0 + j)];
+          p.dst[j] = block_mapping[2 * (i0 + j) + 1];
+        }
+        hipLaunchKernelGGL(swap_blocks_kernel, dim3(np, (unsigned)ysplit), dim3(256), 0, s, ksrc,
+                           kdst, p, block_bytes);
+      }
+      VLA_HIP_CHECK(hipGetLastError());
+      return VLA_OK;
+    }
+  }
   int i = 0;
   while (i < num_pairs) {
     const int64_t s0 = block_mapping[2 * i], d0 = block_mapping[2 * i + 1];
-    if (s0 < 0 || d0 < 0) return VLA_ERR_ARG;
     int run = 1;  // consecutive (src+1, dst+1) pairs collapse into one copy
     while (i + run < num_pairs && block_mapping[2 * (i + run)] == s0 + run &&
            block_mapping[2 * (i + run) + 1] == d0 + run)
