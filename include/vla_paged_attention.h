@@ -39,7 +39,7 @@ extern "C" {
 #define VLA_ERR_DTYPE 3        /* "Unsupported input type of kv cache" amd/quant_utils.cuh:553 */
 #define VLA_ERR_KV_DTYPE 4     /* "Unsupported data type of kv cache"  amd/quant_utils.cuh:569 */
 #define VLA_ERR_ARG 5          /* inconsistent sizes / null pointers */
-#define VLA_ERR_BLOCKSPARSE 6  /* blocksparse_vert_stride > 1 is not implemented */
+#define VLA_ERR_BLOCKSPARSE 6  /* blocksparse_vert_stride > 1 with blocksparse_block_size <= 0 */
 #define VLA_ERR_HIP 7          /* a HIP runtime call failed (see vla_last_hip_error) */
 #define VLA_ERR_QUANT_SHAPE 8  /* AWQ/GPTQ shape constraint, gemm_kernels.cu:515-522 */
 

@@ -51,6 +51,8 @@ def lib():
             getattr(_lib, n).argtypes = [C.c_uint8]
         _lib.oracle_paged_attention_v1.restype = C.c_int
         _lib.oracle_paged_attention_v2.restype = C.c_int
+        _lib.oracle_paged_attention_v1_bs.restype = C.c_int
+        _lib.oracle_paged_attention_v2_bs.restype = C.c_int
         _lib.oracle_num_threads.restype = C.c_int
     return _lib
 
@@ -147,24 +149,33 @@ def _attn_args(query, key_cache, value_cache, block_tables, seq_lens):
     return S, Hq, D, NB, Hkv, BS, x, bt, sl
 
 
+def _bsp(blocksparse):
+    """blocksparse: None or (tp_rank, local_blocks, vert_stride, block_size, head_sliding_step)."""
+    if blocksparse is None:
+        return None
+    return np.ascontiguousarray(blocksparse, dtype=np.int32)
+
+
 def paged_attention_v1(query, key_cache, value_cache, block_tables, seq_lens, scale, dt,
-                       kv=KV_AUTO, kv_scale=1.0, alibi_slopes=None):
+                       kv=KV_AUTO, kv_scale=1.0, alibi_slopes=None, blocksparse=None):
     """query: [S, Hq, D] storage array (contiguous). Returns out storage array."""
     S, Hq, D, NB, Hkv, BS, x, bt, sl = _attn_args(query, key_cache, value_cache, block_tables,
                                                   seq_lens)
     out = np.zeros((S, Hq, D), dtype=scalar_np_dtype(dt))
     al = None if alibi_slopes is None else np.ascontiguousarray(alibi_slopes, dtype=np.float32)
-    rc = lib().oracle_paged_attention_v1(
+    bsp = _bsp(blocksparse)
+    rc = lib().oracle_paged_attention_v1_bs(
         _p(out), _p(_c(query)), _p(_c(key_cache)), _p(_c(value_cache)), C.c_int(S), C.c_int(Hq),
         C.c_int(Hkv), C.c_int(D), C.c_int(BS), C.c_int(x), C.c_float(scale), _p(bt), _p(sl),
         C.c_int(bt.shape[1]), _p(al), C.c_int64(Hq * D), C.c_int64(Hkv * D * BS),
-        C.c_int64(D * BS), C.c_int(dt), C.c_int(kv), C.c_float(kv_scale))
+        C.c_int64(D * BS), C.c_int(dt), C.c_int(kv), C.c_float(kv_scale), _p(bsp))
     assert rc == 0
     return out
 
 
 def paged_attention_v2(query, key_cache, value_cache, block_tables, seq_lens, scale, dt,
-                       kv=KV_AUTO, kv_scale=1.0, alibi_slopes=None, max_seq_len=None):
+                       kv=KV_AUTO, kv_scale=1.0, alibi_slopes=None, max_seq_len=None,
+                       blocksparse=None):
     """Returns (out, exp_sums, max_logits, tmp_out)."""
     S, Hq, D, NB, Hkv, BS, x, bt, sl = _attn_args(query, key_cache, value_cache, block_tables,
                                                   seq_lens)
@@ -176,12 +187,13 @@ def paged_attention_v2(query, key_cache, value_cache, block_tables, seq_lens, sc
     es = np.zeros((S, Hq, P), dtype=np.float32)
     ml = np.zeros((S, Hq, P), dtype=np.float32)
     al = None if alibi_slopes is None else np.ascontiguousarray(alibi_slopes, dtype=np.float32)
-    rc = lib().oracle_paged_attention_v2(
+    bsp = _bsp(blocksparse)
+    rc = lib().oracle_paged_attention_v2_bs(
         _p(out), _p(es), _p(ml), _p(tmp), _p(_c(query)), _p(_c(key_cache)), _p(_c(value_cache)),
         C.c_int(S), C.c_int(Hq), C.c_int(Hkv), C.c_int(D), C.c_int(BS), C.c_int(x),
         C.c_float(scale), _p(bt), _p(sl), C.c_int(bt.shape[1]), C.c_int(P), _p(al),
         C.c_int64(Hq * D), C.c_int64(Hkv * D * BS), C.c_int64(D * BS), C.c_int(dt), C.c_int(kv),
-        C.c_float(kv_scale))
+        C.c_float(kv_scale), _p(bsp))
     assert rc == 0
     return out, es, ml, tmp
 

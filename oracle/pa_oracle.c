@@ -236,7 +236,21 @@ void oracle_swap_blocks(const void* src, void* dst, const int64_t* block_mapping
  * max (:313-330), __expf and sum (:333-339), inv = 1 / (sum + 1e-6) (:342), probabilities
  * rounded to the model dtype before the value product (:398-400), fp32 accumulate, output
  * rounded to the model dtype (:492).  Returns max and exp_sum through the pointers. */
-static void attend_range(float* out_f32 /*[D], written already rounded to dt*/, const float* qf,
+/* Block-sparse attention (csrc/attention/attention_kernels.cu:209-254, :385-393): a KV block is
+ * attended when its sparse block is "remote" ((k_bs + offset) % vert_stride == 0) or "local"
+ * (k_bs > q_bs - local_blocks); skipped blocks get logit -FLT_MAX and no value product.
+ * offset slides with the query head (head_sliding_step >= 0) or the KV head (< 0). */
+typedef struct { int vert_stride, local_blocks, bs_block_size, offset; } BsCtx;
+
+static inline int bs_attended(const BsCtx* bs, int block_idx, int block_size, int seq_len) {
+  if (!bs) return 1;
+  int k_bs = block_idx * block_size / bs->bs_block_size;
+  int q_bs = (seq_len - 1) / bs->bs_block_size;
+  return ((k_bs + bs->offset) % bs->vert_stride == 0) || (k_bs > q_bs - bs->local_blocks);
+}
+
+static void attend_range(const BsCtx* bs,
+                         float* out_f32 /*[D], written already rounded to dt*/, const float* qf,
                          const void* k_cache, const void* v_cache, int kv_head, int head_size,
                          int block_size, int x, float scale, const int* block_table, int seq_len,
                          int tok_begin, int tok_end, float alibi_slope, int64_t kv_block_stride,
@@ -245,6 +259,10 @@ static void attend_range(float* out_f32 /*[D], written already rounded to dt*/, 
   int n = tok_end - tok_begin;
   float qk_max = -3.402823466e+38f;
   for (int t = tok_begin; t < tok_end; ++t) {
+    if (!bs_attended(bs, t / block_size, block_size, seq_len)) {
+      logits[t - tok_begin] = -3.402823466e+38f;
+      continue;
+    }
     int64_t blk = block_table[t / block_size];
     int off = t % block_size;
     int64_t base = blk * kv_block_stride + (int64_t)kv_head * kv_head_stride;
@@ -269,6 +287,7 @@ static void attend_range(float* out_f32 /*[D], written already rounded to dt*/, 
   for (int d = 0; d < head_size; ++d) {
     float acc = 0.f;
     for (int t = tok_begin; t < tok_end; ++t) {
+      if (!bs_attended(bs, t / block_size, block_size, seq_len)) continue;
       int64_t blk = block_table[t / block_size];
       int off = t % block_size;
       int64_t vi = blk * kv_block_stride + (int64_t)kv_head * kv_head_stride +
@@ -284,12 +303,20 @@ static void attend_range(float* out_f32 /*[D], written already rounded to dt*/, 
 /* paged_attention_v1 (csrc/attention/attention_kernels.cu:805-825, launcher :693-767).
  * out,q: [num_seqs, num_heads, head_size] (q row stride q_stride elements);
  * returns 0, or 1 for an unsupported head/block size (the reference raises, :763-765, :800-802). */
-int oracle_paged_attention_v1(void* out, const void* q, const void* k_cache, const void* v_cache,
-                              int num_seqs, int num_heads, int num_kv_heads, int head_size,
-                              int block_size, int x, float scale, const int* block_tables,
-                              const int* seq_lens, int max_blocks_per_seq, const float* alibi_slopes,
-                              int64_t q_stride, int64_t kv_block_stride, int64_t kv_head_stride,
-                              int dt, int kv, float kv_scale) {
+/* bsp: NULL (dense) or {tp_rank, local_blocks, vert_stride, bs_block_size, head_sliding_step} */
+static BsCtx bs_ctx(const int* bsp, int num_heads, int num_kv_heads, int head, int kv_head) {
+  BsCtx c = {bsp[2], bsp[1], bsp[3], 0};
+  c.offset = bsp[4] >= 0 ? (bsp[0] * num_heads + head) * bsp[4] + 1
+                         : (bsp[0] * num_kv_heads + kv_head) * (-bsp[4]) + 1;
+  return c;
+}
+
+static int pa_v1_impl(void* out, const void* q, const void* k_cache, const void* v_cache,
+                      int num_seqs, int num_heads, int num_kv_heads, int head_size,
+                      int block_size, int x, float scale, const int* block_tables,
+                      const int* seq_lens, int max_blocks_per_seq, const float* alibi_slopes,
+                      int64_t q_stride, int64_t kv_block_stride, int64_t kv_head_stride,
+                      int dt, int kv, float kv_scale, const int* bsp) {
   if (num_heads % num_kv_heads) return 1;
   int qpk = num_heads / num_kv_heads;
   int max_len = 0;
@@ -306,8 +333,10 @@ int oracle_paged_attention_v1(void* out, const void* q, const void* k_cache, con
         float mx, sm;
         for (int d = 0; d < head_size; ++d)
           qf[d] = load_scalar(q, (int64_t)s * q_stride + (int64_t)h * head_size + d, dt);
-        attend_range(of, qf, k_cache, v_cache, h / qpk, head_size, block_size, x, scale,
-                     block_tables + (int64_t)s * max_blocks_per_seq, seq_len, 0, seq_len,
+        BsCtx bc;
+        if (bsp) bc = bs_ctx(bsp, num_heads, num_kv_heads, h, h / qpk);
+        attend_range(bsp ? &bc : NULL, of, qf, k_cache, v_cache, h / qpk, head_size, block_size,
+                     x, scale, block_tables + (int64_t)s * max_blocks_per_seq, seq_len, 0, seq_len,
                      alibi_slopes ? alibi_slopes[h] : 0.f, kv_block_stride, kv_head_stride, dt,
                      kv, kv_scale, logits, &mx, &sm);
         for (int d = 0; d < head_size; ++d)
@@ -319,17 +348,42 @@ int oracle_paged_attention_v1(void* out, const void* q, const void* k_cache, con
   return 0;
 }
 
+int oracle_paged_attention_v1(void* out, const void* q, const void* k_cache, const void* v_cache,
+                              int num_seqs, int num_heads, int num_kv_heads, int head_size,
+                              int block_size, int x, float scale, const int* block_tables,
+                              const int* seq_lens, int max_blocks_per_seq, const float* alibi_slopes,
+                              int64_t q_stride, int64_t kv_block_stride, int64_t kv_head_stride,
+                              int dt, int kv, float kv_scale) {
+  return pa_v1_impl(out, q, k_cache, v_cache, num_seqs, num_heads, num_kv_heads, head_size,
+                    block_size, x, scale, block_tables, seq_lens, max_blocks_per_seq, alibi_slopes,
+                    q_stride, kv_block_stride, kv_head_stride, dt, kv, kv_scale, NULL);
+}
+
+/* the block-sparse form (is_block_sparse = vert_stride > 1, attention_kernels.cu:821) */
+int oracle_paged_attention_v1_bs(void* out, const void* q, const void* k_cache, const void* v_cache,
+                                 int num_seqs, int num_heads, int num_kv_heads, int head_size,
+                                 int block_size, int x, float scale, const int* block_tables,
+                                 const int* seq_lens, int max_blocks_per_seq,
+                                 const float* alibi_slopes, int64_t q_stride,
+                                 int64_t kv_block_stride, int64_t kv_head_stride, int dt, int kv,
+                                 float kv_scale, const int* bsp) {
+  return pa_v1_impl(out, q, k_cache, v_cache, num_seqs, num_heads, num_kv_heads, head_size,
+                    block_size, x, scale, block_tables, seq_lens, max_blocks_per_seq, alibi_slopes,
+                    q_stride, kv_block_stride, kv_head_stride, dt, kv, kv_scale,
+                    bsp && bsp[2] > 1 ? bsp : NULL);
+}
+
 /* paged_attention_v2 (csrc/attention/attention_kernels.cu:984-1014; partition kernel :534-562
  * over 512-token partitions, :846; reduce kernel :567-669).  exp_sums/max_logits:
  * [num_seqs, num_heads, P] f32, tmp_out: [num_seqs, num_heads, P, head_size] model dtype, P =
  * max_num_partitions.  Partitions past a sequence's end are left untouched (:116-119). */
-int oracle_paged_attention_v2(void* out, float* exp_sums, float* max_logits, void* tmp_out,
-                              const void* q, const void* k_cache, const void* v_cache,
-                              int num_seqs, int num_heads, int num_kv_heads, int head_size,
-                              int block_size, int x, float scale, const int* block_tables,
-                              const int* seq_lens, int max_blocks_per_seq, int max_num_partitions,
-                              const float* alibi_slopes, int64_t q_stride, int64_t kv_block_stride,
-                              int64_t kv_head_stride, int dt, int kv, float kv_scale) {
+static int pa_v2_impl(void* out, float* exp_sums, float* max_logits, void* tmp_out,
+                      const void* q, const void* k_cache, const void* v_cache,
+                      int num_seqs, int num_heads, int num_kv_heads, int head_size,
+                      int block_size, int x, float scale, const int* block_tables,
+                      const int* seq_lens, int max_blocks_per_seq, int max_num_partitions,
+                      const float* alibi_slopes, int64_t q_stride, int64_t kv_block_stride,
+                      int64_t kv_head_stride, int dt, int kv, float kv_scale, const int* bsp) {
   const int PART = 512;
   if (num_heads % num_kv_heads) return 1;
   int qpk = num_heads / num_kv_heads;
@@ -349,8 +403,10 @@ int oracle_paged_attention_v2(void* out, float* exp_sums, float* max_logits, voi
         for (int p = 0; p < np && p < max_num_partitions; ++p) {
           int b = p * PART, e = b + PART < seq_len ? b + PART : seq_len;
           float mx, sm;
-          attend_range(of, qf, k_cache, v_cache, h / qpk, head_size, block_size, x, scale,
-                       block_tables + (int64_t)s * max_blocks_per_seq, seq_len, b, e,
+          BsCtx bc;
+          if (bsp) bc = bs_ctx(bsp, num_heads, num_kv_heads, h, h / qpk);
+          attend_range(bsp ? &bc : NULL, of, qf, k_cache, v_cache, h / qpk, head_size, block_size,
+                       x, scale, block_tables + (int64_t)s * max_blocks_per_seq, seq_len, b, e,
                        alibi_slopes ? alibi_slopes[h] : 0.f, kv_block_stride, kv_head_stride, dt,
                        kv, kv_scale, logits, &mx, &sm);
           max_logits[sh * max_num_partitions + p] = mx;
@@ -386,6 +442,34 @@ int oracle_paged_attention_v2(void* out, float* exp_sums, float* max_logits, voi
     free(logits); free(qf); free(of);
   }
   return 0;
+}
+
+int oracle_paged_attention_v2(void* out, float* exp_sums, float* max_logits, void* tmp_out,
+                              const void* q, const void* k_cache, const void* v_cache,
+                              int num_seqs, int num_heads, int num_kv_heads, int head_size,
+                              int block_size, int x, float scale, const int* block_tables,
+                              const int* seq_lens, int max_blocks_per_seq, int max_num_partitions,
+                              const float* alibi_slopes, int64_t q_stride, int64_t kv_block_stride,
+                              int64_t kv_head_stride, int dt, int kv, float kv_scale) {
+  return pa_v2_impl(out, exp_sums, max_logits, tmp_out, q, k_cache, v_cache, num_seqs, num_heads,
+                    num_kv_heads, head_size, block_size, x, scale, block_tables, seq_lens,
+                    max_blocks_per_seq, max_num_partitions, alibi_slopes, q_stride,
+                    kv_block_stride, kv_head_stride, dt, kv, kv_scale, NULL);
+}
+
+int oracle_paged_attention_v2_bs(void* out, float* exp_sums, float* max_logits, void* tmp_out,
+                                 const void* q, const void* k_cache, const void* v_cache,
+                                 int num_seqs, int num_heads, int num_kv_heads, int head_size,
+                                 int block_size, int x, float scale, const int* block_tables,
+                                 const int* seq_lens, int max_blocks_per_seq,
+                                 int max_num_partitions, const float* alibi_slopes,
+                                 int64_t q_stride, int64_t kv_block_stride, int64_t kv_head_stride,
+                                 int dt, int kv, float kv_scale, const int* bsp) {
+  return pa_v2_impl(out, exp_sums, max_logits, tmp_out, q, k_cache, v_cache, num_seqs, num_heads,
+                    num_kv_heads, head_size, block_size, x, scale, block_tables, seq_lens,
+                    max_blocks_per_seq, max_num_partitions, alibi_slopes, q_stride,
+                    kv_block_stride, kv_head_stride, dt, kv, kv_scale,
+                    bsp && bsp[2] > 1 ? bsp : NULL);
 }
 
 /* ------------------------------------------------------- int4 weight quantisation */

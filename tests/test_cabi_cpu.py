@@ -48,8 +48,8 @@ def test_argument_validation_without_gpu():
                                   512, 8192, 1024, 0, 0, 1.0, 0, 0, 0, 64, 0, None)
     assert rc == 5  # heads not divisible
     rc = L.vla_paged_attention_v1(one, one, one, one, 1, 8, 8, 64, 16, 1.0, one, one, 4, 64, None,
-                                  512, 8192, 1024, 0, 0, 1.0, 0, 0, 8, 64, 0, None)
-    assert rc == 6  # blocksparse
+                                  512, 8192, 1024, 0, 0, 1.0, 0, 0, 8, 0, 0, None)
+    assert rc == 6  # blocksparse with a non-positive sparse block size
     assert L.vla_awq_gemm(one, one, one, one, one, 4, 128, 32, 128, None) == 8
     assert L.vla_gptq_gemm(one, one, one, one, None, one, 4, 64, 128, 1, 1, 8, None) == 8
     assert L.vla_swap_blocks(one, one, one, 1, 64, 9, None) == 5

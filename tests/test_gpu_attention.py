@@ -280,3 +280,69 @@ def test_full_size_properties(ops, kv_fp8):
     out3 = v1(kc2, vc2, bt2)
     torch.cuda.synchronize()
     assert torch.equal(out1, out3)
+
+
+# ---------------------------------------------------------------- block-sparse attention
+# The reference's block-sparse variant of the same kernels (is_block_sparse = vert_stride > 1,
+# csrc/attention/attention_kernels.cu:209-254, :385-393, :821; its test:
+# tests/kernels/test_blocksparse_attention.py:141-306 with local_blocks 16, vert_stride 8,
+# sparse block size 64, head sliding step 0 and 1).  Expectation: the oracle's restatement of the
+# mask, plus an independent float64 softmax over the attended tokens only.
+def _bs_mask(seq_len, block_size, head, kv_head, hq, hkv, tp_rank, local_blocks, vert_stride,
+             bs_block_size, step):
+    offset = ((tp_rank * hq + head) * step + 1) if step >= 0 else ((tp_rank * hkv + kv_head) * (-step) + 1)
+    t = np.arange(seq_len)
+    k_bs = (t // block_size) * block_size // bs_block_size
+    q_bs = (seq_len - 1) // bs_block_size
+    return ((k_bs + offset) % vert_stride == 0) | (k_bs > q_bs - local_blocks)
+
+
+@pytest.mark.parametrize("version", ["v1", "v2"])
+@pytest.mark.parametrize("kv_fp8", [False, True])
+@pytest.mark.parametrize("params", [(0, 16, 8, 64, 0), (0, 2, 4, 64, 1), (1, 1, 3, 32, -1), (0, 4, 2, 16, 2)])
+@pytest.mark.parametrize("dt", [O.DT_F16, O.DT_BF16])
+def test_blocksparse_attention(ops, version, kv_fp8, params, dt):
+    tp_rank, local_blocks, vert_stride, bs_block_size, step = params
+    c = T.make_attention_case(zlib.crc32(repr((version, kv_fp8, params, dt)).encode()), 5, (8, 2), 128,
+                              16, dt, kv_fp8, False, 1500)
+    out = torch.empty_like(c.t_q)
+    kvd = "fp8" if kv_fp8 else "auto"
+    bs_args = (tp_rank, local_blocks, vert_stride, bs_block_size, step)
+    if version == "v1":
+        ops.paged_attention_v1(out, c.t_q, c.t_kc, c.t_vc, c.hkv, c.scale, c.t_bt, c.t_sl, c.bs,
+                               c.max_seq_len, None, kvd, 1.0, *bs_args)
+        want = O.paged_attention_v1(c.q, c.kc, c.vc, c.block_tables, c.seq_lens, c.scale, dt, kv=c.kv,
+                                    blocksparse=bs_args)
+    else:
+        S, H, D = out.shape
+        P = (c.max_seq_len + 511) // 512
+        tmp = torch.empty((S, H, P, D), dtype=out.dtype, device="cuda")
+        es = torch.empty((S, H, P), dtype=torch.float32, device="cuda")
+        ml = torch.empty_like(es)
+        ops.paged_attention_v2(out, es, ml, tmp, c.t_q, c.t_kc, c.t_vc, c.hkv, c.scale, c.t_bt,
+                               c.t_sl, c.bs, c.max_seq_len, None, kvd, 1.0, *bs_args)
+        want = O.paged_attention_v2(c.q, c.kc, c.vc, c.block_tables, c.seq_lens, c.scale, dt, kv=c.kv,
+                                    max_seq_len=c.max_seq_len, blocksparse=bs_args)[0]
+    torch.cuda.synchronize()
+    got = out.float().cpu().numpy()
+    atol = 1e-2 if kv_fp8 else (1e-3 if dt == O.DT_F16 else 2e-3)
+    np.testing.assert_allclose(got, O.from_bits(want, dt), atol=atol, rtol=1e-5)
+    # independent float64 expectation: softmax over the attended tokens only
+    if kv_fp8:
+        kc = O.from_bits(O.convert_fp8(c.kc, dt, False, 1.0), dt).astype(np.float64)
+        vc = O.from_bits(O.convert_fp8(c.vc, dt, False, 1.0), dt).astype(np.float64)
+    else:
+        kc, vc = O.from_bits(c.kc, dt).astype(np.float64), O.from_bits(c.vc, dt).astype(np.float64)
+    q = O.from_bits(c.q, dt).astype(np.float64)
+    for s in range(len(c.seq_lens)):
+        n = int(c.seq_lens[s])
+        t = np.arange(n)
+        blk, off = c.block_tables[s][t // c.bs], t % c.bs
+        k = kc[blk, :, :, off, :].reshape(n, c.hkv, c.d)
+        v = vc[blk, :, :, off]
+        for h in range(c.hq):
+            m = _bs_mask(n, c.bs, h, h // (c.hq // c.hkv), c.hq, c.hkv, *bs_args)
+            logits = c.scale * (k[m, h // (c.hq // c.hkv), :] @ q[s, h])
+            p = np.exp(logits - logits.max())
+            ref = (p / p.sum()) @ v[m, h // (c.hq // c.hkv), :]
+            np.testing.assert_allclose(got[s, h], ref, atol=3 * atol, rtol=1e-3)

@@ -20,7 +20,7 @@ extern "C" const char* vla_status_string(int status) {
     case VLA_ERR_DTYPE: return "Unsupported input type of kv cache";
     case VLA_ERR_KV_DTYPE: return "Unsupported data type of kv cache";
     case VLA_ERR_ARG: return "Invalid argument";
-    case VLA_ERR_BLOCKSPARSE: return "Blocksparse paged attention is not supported by this backend";
+    case VLA_ERR_BLOCKSPARSE: return "Invalid blocksparse parameters (block size must be positive)";
     case VLA_ERR_HIP: return "HIP runtime error";
     case VLA_ERR_QUANT_SHAPE: return "Unsupported quantized weight shape";
     default: return "unknown status";
@@ -61,9 +61,7 @@ static int check_attn(const void* out, const void* query, const void* kc, const 
   if (kv_dtype != VLA_KV_AUTO && kv_dtype != VLA_KV_FP8_E4M3) return VLA_ERR_KV_DTYPE;
   if (!block_size_supported(block_size)) return VLA_ERR_BLOCK_SIZE;
   if (!head_size_supported(head_size)) return VLA_ERR_HEAD_SIZE;
-  // the reference switches to its block-sparse template when vert_stride > 1
-  // (attention_kernels.cu:821); that variant is outside this backend
-  if (vert_stride > 1) return VLA_ERR_BLOCKSPARSE;
+  (void)vert_stride;
   return VLA_OK;
 }
 
@@ -76,8 +74,8 @@ extern "C" int vla_paged_attention_v1(
     int blocksparse_vert_stride, int blocksparse_block_size, int blocksparse_head_sliding_step,
     void* stream) {
   (void)hipGetLastError();  // a stale error of some earlier HIP call must not fail this one
-  (void)max_seq_len; (void)tp_rank; (void)blocksparse_local_blocks;
-  (void)blocksparse_block_size; (void)blocksparse_head_sliding_step;
+  (void)max_seq_len;
+  if (blocksparse_vert_stride > 1 && blocksparse_block_size <= 0) return VLA_ERR_BLOCKSPARSE;
   int rc = check_attn(out, query, key_cache, value_cache, num_seqs, num_heads, num_kv_heads,
                       head_size, block_size, block_tables, seq_lens, max_num_blocks_per_seq,
                       dtype, kv_dtype, blocksparse_vert_stride);
@@ -91,8 +89,14 @@ extern "C" int vla_paged_attention_v1(
   p.max_num_blocks_per_seq = max_num_blocks_per_seq; p.max_num_partitions = 0;
   p.scale = scale; p.kv_scale = kv_scale;
   p.q_stride = q_stride; p.kv_block_stride = kv_block_stride; p.kv_head_stride = kv_head_stride;
+  p.bs_vert_stride = blocksparse_vert_stride; p.bs_local_blocks = blocksparse_local_blocks;
+  p.bs_block_size = blocksparse_block_size; p.bs_head_sliding_step = blocksparse_head_sliding_step;
+  p.tp_rank = tp_rank;
   hipStream_t s = (hipStream_t)stream;
-  rc = g_attention_path == 1 ? -1 : launch_paged_attention_mfma(p, dtype, kv_dtype, s);
+  // the block-sparse variant (vert_stride > 1, ref attention_kernels.cu:821) runs on the generic
+  // kernel only
+  const bool generic_only = g_attention_path == 1 || blocksparse_vert_stride > 1;
+  rc = generic_only ? -1 : launch_paged_attention_mfma(p, dtype, kv_dtype, s);
   if (rc >= 0) return rc;
   return launch_paged_attention_generic(p, dtype, kv_dtype, s);
 }
@@ -106,8 +110,7 @@ extern "C" int vla_paged_attention_v2(
     float kv_scale, int tp_rank, int blocksparse_local_blocks, int blocksparse_vert_stride,
     int blocksparse_block_size, int blocksparse_head_sliding_step, void* stream) {
   (void)hipGetLastError();  // a stale error of some earlier HIP call must not fail this one
-  (void)tp_rank; (void)blocksparse_local_blocks;
-  (void)blocksparse_block_size; (void)blocksparse_head_sliding_step;
+  if (blocksparse_vert_stride > 1 && blocksparse_block_size <= 0) return VLA_ERR_BLOCKSPARSE;
   int rc = check_attn(out, query, key_cache, value_cache, num_seqs, num_heads, num_kv_heads,
                       head_size, block_size, block_tables, seq_lens, max_num_blocks_per_seq,
                       dtype, kv_dtype, blocksparse_vert_stride);
@@ -124,8 +127,12 @@ extern "C" int vla_paged_attention_v2(
   p.max_num_blocks_per_seq = max_num_blocks_per_seq; p.max_num_partitions = P;
   p.scale = scale; p.kv_scale = kv_scale;
   p.q_stride = q_stride; p.kv_block_stride = kv_block_stride; p.kv_head_stride = kv_head_stride;
+  p.bs_vert_stride = blocksparse_vert_stride; p.bs_local_blocks = blocksparse_local_blocks;
+  p.bs_block_size = blocksparse_block_size; p.bs_head_sliding_step = blocksparse_head_sliding_step;
+  p.tp_rank = tp_rank;
   hipStream_t s = (hipStream_t)stream;
-  rc = g_attention_path == 1 ? -1 : launch_paged_attention_mfma(p, dtype, kv_dtype, s);
+  const bool generic_only = g_attention_path == 1 || blocksparse_vert_stride > 1;
+  rc = generic_only ? -1 : launch_paged_attention_mfma(p, dtype, kv_dtype, s);
   if (rc < 0) rc = launch_paged_attention_generic(p, dtype, kv_dtype, s);
   if (rc != VLA_OK) return rc;
   return launch_paged_attention_v2_reduce(out, exp_sums, max_logits, tmp_out, seq_lens, num_seqs,

@@ -7,7 +7,9 @@
 //
 // Math follows the reference kernel body (csrc/attention/attention_kernels.cu:90-496):
 // fp32 logits = scale * q.k (+ alibi), probabilities rounded to the model dtype before the
-// value product, fp32 accumulation, normaliser 1 / (sum + 1e-6).
+// value product, fp32 accumulation, normaliser 1 / (sum + 1e-6).  Block-sparse attention
+// (:209-254, :385-393) is a per-KV-block mask: a skipped block's tokens get logit -FLT_MAX and
+// its values are never loaded.
 #include "vla_common.h"
 
 #include <float.h>
@@ -85,7 +87,7 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
   return r;
 }
 
-template <class S, bool FP8, bool PARTITIONED>
+template <class S, bool FP8, bool PARTITIONED, bool SPARSE>
 __global__ __launch_bounds__(kThreads) void pa_generic_kernel(AttnParams p) {
   using T = typename S::T;
   using C = Cache<S, FP8>;
@@ -104,6 +106,20 @@ __global__ __launch_bounds__(kThreads) void pa_generic_kernel(AttnParams p) {
   const float alibi = p.alibi_slopes ? p.alibi_slopes[head] : 0.f;
   const int* bt = p.block_tables + (int64_t)seq * p.max_num_blocks_per_seq;
   const int64_t head_off = (int64_t)kv_head * p.kv_head_stride;
+
+  // block-sparse mask of KV block b: attended when its sparse block is "remote" or "local"
+  int bs_offset = 0, q_bs = 0;
+  if constexpr (SPARSE) {
+    q_bs = (seq_len - 1) / p.bs_block_size;
+    bs_offset = p.bs_head_sliding_step >= 0
+                    ? (p.tp_rank * p.num_heads + head) * p.bs_head_sliding_step + 1
+                    : (p.tp_rank * p.num_kv_heads + kv_head) * (-p.bs_head_sliding_step) + 1;
+  }
+  auto attended = [&](int block_idx) -> bool {
+    if constexpr (!SPARSE) return true;
+    const int k_bs = block_idx * BS / p.bs_block_size;
+    return ((k_bs + bs_offset) % p.bs_vert_stride == 0) || (k_bs > q_bs - p.bs_local_blocks);
+  };
 
   __shared__ float q_s[256];
   __shared__ __attribute__((aligned(16))) float logits[kChunk];
@@ -128,6 +144,10 @@ __global__ __launch_bounds__(kThreads) void pa_generic_kernel(AttnParams p) {
     float lmax = -FLT_MAX;
     for (int i = tid; i < n; i += kThreads) {
       const int t = c0 + i;
+      if (!attended(t / BS)) {
+        logits[i] = -FLT_MAX;
+        continue;
+      }
       const int64_t blk = bt[t / BS];
       const int off = t % BS;
       const int64_t base = blk * p.kv_block_stride + head_off + (int64_t)off * X;
@@ -162,6 +182,7 @@ __global__ __launch_bounds__(kThreads) void pa_generic_kernel(AttnParams p) {
     if (pv_active) {
       const int b0 = c0 / BS, nb = (n + BS - 1) / BS;
       for (int b = grp; b < nb; b += ngroups) {
+        if (!attended(b0 + b)) continue;
         const int64_t blk = bt[b0 + b];
         const int64_t row = blk * p.kv_block_stride + head_off + (int64_t)d * BS;
         const int valid = min(BS, n - b * BS);
@@ -253,10 +274,18 @@ __global__ __launch_bounds__(128) void pa_v2_reduce_kernel(
 template <class S, bool FP8>
 void launch_generic_t(const AttnParams& p, hipStream_t s) {
   dim3 grid(p.num_heads, p.num_seqs, p.max_num_partitions > 0 ? p.max_num_partitions : 1);
-  if (p.max_num_partitions > 0)
-    hipLaunchKernelGGL((pa_generic_kernel<S, FP8, true>), grid, dim3(kThreads), 0, s, p);
-  else
-    hipLaunchKernelGGL((pa_generic_kernel<S, FP8, false>), grid, dim3(kThreads), 0, s, p);
+  const bool sparse = p.bs_vert_stride > 1;
+  if (p.max_num_partitions > 0) {
+    if (sparse)
+      hipLaunchKernelGGL((pa_generic_kernel<S, FP8, true, true>), grid, dim3(kThreads), 0, s, p);
+    else
+      hipLaunchKernelGGL((pa_generic_kernel<S, FP8, true, false>), grid, dim3(kThreads), 0, s, p);
+  } else {
+    if (sparse)
+      hipLaunchKernelGGL((pa_generic_kernel<S, FP8, false, true>), grid, dim3(kThreads), 0, s, p);
+    else
+      hipLaunchKernelGGL((pa_generic_kernel<S, FP8, false, false>), grid, dim3(kThreads), 0, s, p);
+  }
 }
 
 }  // namespace

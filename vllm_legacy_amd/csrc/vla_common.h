@@ -132,6 +132,9 @@ struct AttnParams {
   int max_num_partitions;  // 0 = V1 (whole sequence in one workgroup)
   float scale, kv_scale;
   int64_t q_stride, kv_block_stride, kv_head_stride;
+  // block-sparse attention (ref attention_kernels.cu:209-254); bs_vert_stride <= 1 = dense
+  int bs_vert_stride = 0, bs_local_blocks = 0, bs_block_size = 64, bs_head_sliding_step = 0;
+  int tp_rank = 0;
 };
 
 // implemented in paged_attention_generic.hip / paged_attention_mfma.hip
