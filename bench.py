@@ -28,7 +28,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
+HBM_PEAK_GBS = 8000.0
+HBM_MEASURED_READ_GBS = 6353.0  # MI355X HBM3E spec peak
 
 
 def parse():
@@ -318,6 +319,9 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
+                # linear read-only stream measured on an MI355X with tools/exp/read_bw.hip
+                "peak_measured_read": HBM_MEASURED_READ_GBS,
+                "frac_of_measured_read": round(achieved / HBM_MEASURED_READ_GBS, 4),
                 "traffic": traffic,
                 "algorithmic_bytes_per_launch": algo_bytes,
                 "launch_ms": round(attn_ms, 4),
