@@ -202,6 +202,21 @@ int vla_rotary_embedding(const int64_t* positions, void* query, void* key,
 int vla_silu_and_mul(void* out, const void* input, int num_tokens, int d, int dtype,
                      void* stream);
 
+/* ---- prompt attention ----------------------------------------------------------------------- */
+
+/* Causal self-attention over packed prompt tokens without a cached prefix: what the reference's
+ * ROCm backend computes for prefill with Triton / CK flash attention or its naive masked path
+ * (vllm/attention/backends/rocm_flash_attn.py:305-383).  query/out [T, num_heads, head_size],
+ * key/value [T, num_kv_heads, head_size], row strides in elements; cu_seqlens [num_seqs + 1]
+ * int32 on the device (the reference's seq_start_loc); alibi_slopes [num_heads] f32 or NULL
+ * (bias slope * (j - i)).  fp16 / bf16, head_size 64 or 128; other shapes: VLA_ERR_HEAD_SIZE /
+ * VLA_ERR_DTYPE (the caller keeps its previous path for those). */
+int vla_prefill_attention(void* out, const void* query, const void* key, const void* value,
+                          const int* cu_seqlens, int num_seqs, int max_seqlen, int num_heads,
+                          int num_kv_heads, int head_size, int64_t query_stride,
+                          int64_t key_stride, int64_t value_stride, int64_t out_stride,
+                          float scale, const float* alibi_slopes, int dtype, void* stream);
+
 /* ---- fused forms (same results as the separate calls, fewer launches) ----------------------- */
 
 /* vla_q4_gemm_packed without its reduction launch: when the product was split along K,

@@ -198,6 +198,23 @@ def paged_attention_v2(query, key_cache, value_cache, block_tables, seq_lens, sc
     return out, es, ml, tmp
 
 
+def prefill_attention(q, k, v, seq_lens, scale, dt, alibi_slopes=None):
+    """q [T, Hq, D], k/v [T, Hkv, D] contiguous storage arrays; seq_lens: prompt lengths.
+    Causal attention within each sequence; returns out [T, Hq, D]."""
+    T_, Hq, D = q.shape
+    Hkv = k.shape[1]
+    cu = np.zeros(len(seq_lens) + 1, dtype=np.int32)
+    cu[1:] = np.cumsum(seq_lens)
+    assert cu[-1] == T_
+    out = np.zeros_like(q)
+    al = None if alibi_slopes is None else np.ascontiguousarray(alibi_slopes, dtype=np.float32)
+    lib().oracle_prefill_attention(_p(out), _p(_c(q)), _p(_c(k)), _p(_c(v)), _p(cu),
+                                   C.c_int(len(seq_lens)), C.c_int(Hq), C.c_int(Hkv), C.c_int(D),
+                                   C.c_int64(Hq * D), C.c_int64(Hkv * D), C.c_int64(Hkv * D),
+                                   C.c_int64(Hq * D), C.c_float(scale), _p(al), C.c_int(dt))
+    return out
+
+
 # ------------------------------------------------------------------ int4 weights
 
 

@@ -472,6 +472,56 @@ int oracle_paged_attention_v2_bs(void* out, float* exp_sums, float* max_logits, 
                     bsp && bsp[2] > 1 ? bsp : NULL);
 }
 
+/* ------------------------------------------------------------- prompt (prefill) attention */
+
+/* Causal self-attention over packed prompt tokens, the expectation of the reference's kernel
+ * tests for the prompt path (ref_masked_attention, tests/kernels/test_attention.py:43-55, used
+ * per sequence with a lower-triangular mask, :333-366): logits = scale * q.k in fp32 (+ ALiBi
+ * bias slope * (j - i), vllm/attention/backends/rocm_flash_attn.py:153-173), softmax in fp32
+ * rounded to the model dtype, value product accumulated in fp32, output rounded.
+ * q/out: [T, Hq, D], k/v: [T, Hkv, D] with row strides in elements; cu_seqlens [num_seqs + 1]. */
+void oracle_prefill_attention(void* out, const void* q, const void* k, const void* v,
+                              const int* cu_seqlens, int num_seqs, int num_heads, int num_kv_heads,
+                              int head_size, int64_t q_stride, int64_t k_stride, int64_t v_stride,
+                              int64_t out_stride, float scale, const float* alibi_slopes, int dt) {
+  int qpk = num_heads / num_kv_heads;
+#pragma omp parallel for collapse(2) schedule(dynamic, 1)
+  for (int s = 0; s < num_seqs; ++s) {
+    for (int h = 0; h < num_heads; ++h) {
+      int start = cu_seqlens[s], n = cu_seqlens[s + 1] - start;
+      float* logits = (float*)malloc(sizeof(float) * (size_t)(n + 1));
+      float* acc = (float*)malloc(sizeof(float) * (size_t)head_size);
+      int kvh = h / qpk;
+      for (int i = 0; i < n; ++i) {
+        float mx = -3.402823466e+38f;
+        for (int j = 0; j <= i; ++j) {
+          float dot = 0.f;
+          for (int d = 0; d < head_size; ++d)
+            dot += load_scalar(q, (int64_t)(start + i) * q_stride + (int64_t)h * head_size + d, dt) *
+                   load_scalar(k, (int64_t)(start + j) * k_stride + (int64_t)kvh * head_size + d, dt);
+          float x = scale * dot;
+          if (alibi_slopes) x += alibi_slopes[h] * (float)(j - i);
+          logits[j] = x;
+          mx = fmaxf(mx, x);
+        }
+        float sum = 0.f;
+        for (int j = 0; j <= i; ++j) { logits[j] = expf(logits[j] - mx); sum += logits[j]; }
+        for (int d = 0; d < head_size; ++d) acc[d] = 0.f;
+        for (int j = 0; j <= i; ++j) {
+          float pj = round_scalar(logits[j] / sum, dt);
+          for (int d = 0; d < head_size; ++d)
+            acc[d] += pj * load_scalar(v, (int64_t)(start + j) * v_stride +
+                                              (int64_t)kvh * head_size + d, dt);
+        }
+        for (int d = 0; d < head_size; ++d)
+          store_scalar(out, (int64_t)(start + i) * out_stride + (int64_t)h * head_size + d, dt,
+                       acc[d]);
+      }
+      free(logits); free(acc);
+    }
+  }
+}
+
 /* ------------------------------------------------------- int4 weight quantisation */
 
 /* AWQ: W[k, 8j + i] = (nib(qweight[k, j], P[i]) - nib(qzeros[k/G, j], P[i])) * scales[k/G, 8j+i]

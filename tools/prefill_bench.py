@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""Kernel study: HIP prompt attention vs torch SDPA on Llama-3-8B head shapes (HIP events)."""
+import json
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from vllm_legacy_amd import _custom_ops as ops  # noqa: E402
+
+
+def timed(fn, iters=5):
+    fn()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(iters):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        fn()
+        e1.record()
+        torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1))
+    return sorted(ts)[len(ts) // 2]
+
+
+def main():
+    dev = torch.device("cuda", 0)
+    hq, hkv, d = 32, 8, 128
+    res = {}
+    for nseq, s in ((8, 4096), (32, 1024), (4, 8192)):
+        t = nseq * s
+        qkv = torch.empty((t, (hq + 2 * hkv) * d), dtype=torch.float16, device=dev).uniform_(-1, 1)
+        q, k, v = [x.view(t, -1, d) for x in qkv.split([hq * d, hkv * d, hkv * d], dim=-1)]
+        out = torch.empty((t, hq, d), dtype=torch.float16, device=dev)
+        cu = torch.arange(0, t + 1, s, dtype=torch.int32, device=dev)
+        ms = timed(lambda: ops.prefill_attention(out, q, k, v, cu, s, d**-0.5))
+        flops = 4.0 * nseq * hq * d * s * (s + 1) / 2
+
+        def sdpa():
+            for i in range(nseq):
+                qs = q[i * s:(i + 1) * s].transpose(0, 1)
+                ks = k[i * s:(i + 1) * s].transpose(0, 1).repeat_interleave(hq // hkv, dim=0)
+                vs = v[i * s:(i + 1) * s].transpose(0, 1).repeat_interleave(hq // hkv, dim=0)
+                torch.nn.functional.scaled_dot_product_attention(qs, ks, vs, is_causal=True, scale=d**-0.5)
+        ms2 = timed(sdpa, iters=3)
+        res[f"{nseq}x{s}"] = {"hip_ms": round(ms, 3), "hip_TFLOPs": round(flops / ms / 1e9, 1),
+                              "sdpa_ms": round(ms2, 3), "sdpa_TFLOPs": round(flops / ms2 / 1e9, 1)}
+    print(json.dumps(res))
+
+
+if __name__ == "__main__":
+    main()

@@ -208,6 +208,29 @@ def paged_attention_v2_raw(out, exp_sum, max_logits, tmp_out, query, key_cache_p
             "paged_attention_v2")
 
 
+def prefill_attention(out: torch.Tensor, query: torch.Tensor, key: torch.Tensor,
+                      value: torch.Tensor, cu_seqlens: torch.Tensor, max_seqlen: int,
+                      scale: float, alibi_slopes: Optional[torch.Tensor] = None) -> None:
+    """Causal attention over packed prompt tokens: query/out [T, Hq, D], key/value [T, Hkv, D]
+    (row-strided views are fine), cu_seqlens [num_seqs + 1] int32 on the device."""
+    _require_cuda(out, query, key, value, cu_seqlens, alibi_slopes)
+    assert cu_seqlens.dtype == torch.int32 and cu_seqlens.is_contiguous()
+    t, hq, d = query.shape
+    hkv = key.shape[1]
+    for x in (out, query, key, value):
+        assert x.stride(2) == 1 and x.stride(1) == d
+    with torch.cuda.device(query.device):
+        check(_lib.lib().vla_prefill_attention(
+            out.data_ptr(), query.data_ptr(), key.data_ptr(), value.data_ptr(),
+            cu_seqlens.data_ptr(), cu_seqlens.numel() - 1, max_seqlen, hq, hkv, d, query.stride(0),
+            key.stride(0), value.stride(0), out.stride(0), scale, _ptr(alibi_slopes), _dt(query),
+            _stream(query.device)), "prefill_attention")
+
+
+def prefill_attention_supported(dtype: torch.dtype, head_size: int) -> bool:
+    return dtype in (torch.float16, torch.bfloat16) and head_size in (64, 128)
+
+
 # ---------------------------------------------------------------- cache ops
 
 

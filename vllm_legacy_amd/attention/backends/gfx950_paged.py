@@ -11,6 +11,8 @@ from typing import Any, Dict, List, Optional, Tuple, Type
 
 import torch
 
+from vllm_legacy_amd import _custom_ops as ops
+
 from vllm_legacy_amd.attention.backends.abstract import (AttentionBackend, AttentionImpl,
                                                          AttentionMetadata)
 from vllm_legacy_amd.attention.ops.paged_attn import PagedAttention, PagedAttentionMetadata
@@ -146,9 +148,23 @@ class Gfx950PagedAttentionImpl(AttentionImpl):
 
         prefill_meta = attn_metadata.prefill_metadata
         if prefill_meta is not None:
-            output[:n_pre] = _causal_prompt_attention(query[:n_pre], key[:n_pre], value[:n_pre],
-                                                      prefill_meta.seq_lens, self.scale,
-                                                      self.num_queries_per_kv)
+            if ops.prefill_attention_supported(query.dtype, self.head_size):
+                # HIP flash-style kernel over the packed prompt tokens; seq_start_loc is the
+                # cumulative prompt length table the reference's metadata carries
+                # (rocm_flash_attn.py:84-88)
+                cu = prefill_meta.seq_start_loc
+                if cu is None:
+                    lens = torch.as_tensor(prefill_meta.seq_lens, dtype=torch.int32)
+                    cu = torch.zeros(len(lens) + 1, dtype=torch.int32)
+                    cu[1:] = torch.cumsum(lens, 0)
+                cu = cu.to(device=query.device, dtype=torch.int32)
+                ops.prefill_attention(output[:n_pre], query[:n_pre], key[:n_pre], value[:n_pre],
+                                      cu, int(prefill_meta.max_prefill_seq_len), self.scale,
+                                      self._alibi(query.device))
+            else:
+                output[:n_pre] = _causal_prompt_attention(query[:n_pre], key[:n_pre],
+                                                          value[:n_pre], prefill_meta.seq_lens,
+                                                          self.scale, self.num_queries_per_kv)
         decode_meta = attn_metadata.decode_metadata
         if decode_meta is not None:
             assert kv_cache is not None, "decode needs a KV cache"
