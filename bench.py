@@ -211,7 +211,10 @@ def main():
         if use_graph:
             try:
                 graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph, stream=stream):
+                # with collectives in the step, other threads (the process group's watchdog) make
+                # HIP calls of their own; they must not invalidate this thread's capture
+                mode = "thread_local" if world > 1 else "global"
+                with torch.cuda.graph(graph, stream=stream, capture_error_mode=mode):
                     step()
             except Exception as e:  # e.g. a collective that cannot be captured
                 if rank == 0:

@@ -727,10 +727,12 @@ __global__ __launch_bounds__(128 * WN) void q4_kernel5(
       return bf;
     };
     auto mma = [&](const u32x4 (&af)[4], const u32x4& bf) {
+      if constexpr (OPT & 8) __builtin_amdgcn_s_setprio(2);
 #pragma unroll
       for (int a = 0; a < 4; ++a)
         acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[a]),
                                                         __builtin_bit_cast(f16x8, bf), acc[a], 0, 0, 0);
+      if constexpr (OPT & 8) __builtin_amdgcn_s_setprio(0);
     };
     u32x4 fa[4], fb[4];
     if constexpr (OPT & 4) {
@@ -1151,6 +1153,10 @@ int main(int argc, char** argv) {
     double md = 0; for (size_t i = 0; i < a.size(); ++i) { double d = fabs((double)a[i] - (double)b[i]); if (d > md) md = d; }
     printf("max |V5 - V0| = %g\n", md);
   }
+  run5<0, 8>("V5 setprio", m, n, k, x, qw, qz, sc, out, iters);
+  run5<0, 2>("V5 andor", m, n, k, x, qw, qz, sc, out, iters);
+  run5<0, 10>("V5 setprio+andor", m, n, k, x, qw, qz, sc, out, iters);
+  return 0;
   run5<ABL_NODEQ, 0>("V5 no dequant", m, n, k, x, qw, qz, sc, out, iters);
   run5<ABL_NOX, 0>("V5 no x staging", m, n, k, x, qw, qz, sc, out, iters);
   run5<ABL_NOW, 0>("V5 no w loads", m, n, k, x, qw, qz, sc, out, iters);
