@@ -79,7 +79,7 @@ __device__ __forceinline__ int v_swz(int row, int ch) {
 }
 
 template <class S, int D>
-__global__ __launch_bounds__(PF_THREADS) void prefill_attention_kernel(PrefillParams p) {
+__global__ __launch_bounds__(PF_THREADS, 2) void prefill_attention_kernel(PrefillParams p) {
   using T = typename S::T;
   constexpr int RB = D * 2;                 // bytes per K/V row in LDS
   constexpr int CH = D / 8;                 // 16-byte chunks per row
@@ -117,7 +117,9 @@ __global__ __launch_bounds__(PF_THREADS) void prefill_attention_kernel(PrefillPa
     for (int ks = 0; ks < KS; ++ks)
       qf[sub][ks] = *reinterpret_cast<const u32x4*>(qp + 8 * g + 32 * ks);
   }
-  const float slope = p.alibi_slopes ? p.alibi_slopes[head] : 0.f;
+  constexpr float kLog2e = 1.4426950408889634f;
+  const float scale2 = p.scale * kLog2e;
+  const float slope2 = p.alibi_slopes ? p.alibi_slopes[head] * kLog2e : 0.f;
 
   f32x4 o[2][ND];
 #pragma unroll
@@ -149,45 +151,48 @@ __global__ __launch_bounds__(PF_THREADS) void prefill_attention_kernel(PrefillPa
     }
   };
 
-  load_tile(0);
   for (int kt = 0; kt < ntiles; ++kt) {
+    // two workgroups share a CU: while this one waits for its tile, the other one computes
+    load_tile(kt);
     __syncthreads();                 // every wave is done reading the previous tile
     store_tile();
     __syncthreads();
-    if (kt + 1 < ntiles) load_tile(kt + 1);
     const int k0 = kt * PF_BN;
     // this wave's queries all precede the tile: nothing to add (wave-uniform)
     if (k0 > q0 + 32 * wave + 31) continue;
 
-    // ---- S^T = K q^T: 4 key blocks x 2 query tiles
-    f32x4 s[2][4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
-      const int row = 16 * t + c;
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-        const u32x4 kf = *reinterpret_cast<const u32x4*>(k_lds + row * RB +
-                                                         16 * k_swz<D>(row, g + 4 * ks));
-        a0 = pf_mfma<S>(kf, qf[0][ks], a0);
-        a1 = pf_mfma<S>(kf, qf[1][ks], a1);
-      }
-      s[0][t] = a0;
-      s[1][t] = a1;
-    }
-
-    // ---- online softmax of query c (per query tile) over this lane's keys
+    // ---- online softmax of query c (per query tile) over this lane's keys, in base 2: logits
+    // are scaled by scale * log2(e) so that every exponential is a bare v_exp_f32.  A tile that
+    // lies entirely below the diagonal of this wave's queries and inside the sequence needs no
+    // mask (wave-uniform test).
+    const bool interior = (k0 + PF_BN - 1 <= q0 + 32 * wave) && (k0 + PF_BN <= seq_len);
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub) {
+      // S^T = K q^T for this query tile: 4 key blocks of 16 (the two query tiles go one after the
+      // other so that only one logit tile is live)
+      f32x4 st[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        const int row = 16 * t + c;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          const u32x4 kf = *reinterpret_cast<const u32x4*>(k_lds + row * RB +
+                                                           16 * k_swz<D>(row, g + 4 * ks));
+          acc = pf_mfma<S>(kf, qf[sub][ks], acc);
+        }
+        st[t] = acc;
+      }
       float mx = -INFINITY;
 #pragma unroll
       for (int t = 0; t < 4; ++t)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const int key = k0 + 16 * t + 4 * g + i;
-          float x = s[sub][t][i] * p.scale + slope * (float)(key - qrow[sub]);
-          x = (key <= qrow[sub] && key < seq_len) ? x : -INFINITY;
-          s[sub][t][i] = x;
+          float x = st[t][i] * scale2;
+          if (slope2 != 0.f) x += slope2 * (float)(key - qrow[sub]);
+          if (!interior) x = (key <= qrow[sub] && key < seq_len) ? x : -INFINITY;
+          st[t][i] = x;
           mx = fmaxf(mx, x);
         }
       mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
@@ -195,14 +200,14 @@ __global__ __launch_bounds__(PF_THREADS) void prefill_attention_kernel(PrefillPa
       const float m_new = fmaxf(m_run[sub], mx);
       // a query with no live key so far keeps m = -inf: use 0 as the reference point then
       const float m_ref = m_new == -INFINITY ? 0.f : m_new;
-      const float alpha = __expf(m_run[sub] - m_ref);
+      const float alpha = __builtin_amdgcn_exp2f(m_run[sub] - m_ref);
       float psum = 0.f;
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         float e[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          e[i] = __expf(s[sub][t][i] - m_ref);
+          e[i] = __builtin_amdgcn_exp2f(st[t][i] - m_ref);
           psum += e[i];
         }
         u32x2 w;
