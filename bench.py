@@ -42,6 +42,8 @@ def parse():
     ap.add_argument("--layers", type=int, default=32)
     ap.add_argument("--quant", default="awq", choices=["awq", "gptq", "none"])
     ap.add_argument("--kv", default="fp8", choices=["fp8", "auto"])
+    ap.add_argument("--dtype", default="f16", choices=["f16", "bf16"],
+                    help="model dtype (the int4 linears need f16; bf16 goes with --quant none)")
     ap.add_argument("--model", default="llama3-8b", choices=["llama3-8b", "llama3-70b", "tiny"])
     ap.add_argument("--no-graph", action="store_true", help="run the step eagerly")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -171,7 +173,10 @@ def main():
     cfg.num_hidden_layers = args.layers
     B, S, BS = args.batch, args.seq, 16
     torch.manual_seed(0)
-    model = LlamaDecodeModel(cfg, quant=args.quant, kv_cache_dtype=args.kv, device=device)
+    model_dtype = torch.float16 if args.dtype == "f16" else torch.bfloat16
+    assert args.quant == "none" or args.dtype == "f16", "AWQ/GPTQ linears are fp16-only"
+    model = LlamaDecodeModel(cfg, quant=args.quant, kv_cache_dtype=args.kv, device=device,
+                             dtype=model_dtype)
     num_blocks = B * (S // BS) + 8
     kv_caches = fill_kv_caches(model, num_blocks, BS, args.kv, device)
 
@@ -305,10 +310,13 @@ def main():
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
-            "dtype": "f16",
+            "dtype": args.dtype,
             "data": "synthetic",
             "config": {
-                "workload": f"{args.model} decode step, {args.quant} int4 weights, {args.kv} KV cache, "
+                "workload": f"{args.model} decode step, "
+                            + (f"{args.quant} int4 weights" if args.quant != "none"
+                               else f"{args.dtype} weights")
+                            + f", {args.kv if args.kv == 'fp8' else args.dtype} KV cache, "
                             f"batch {B}, context {S}, block 16, {args.layers} layers",
                 "parallelism": f"tp{world}",
                 "graph": graph is not None,
