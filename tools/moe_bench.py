@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""Kernel study: quantized Mixtral MoE block at Mixtral-8x7B shapes, routed vs dense execution."""
+import json
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from vllm_legacy_amd.model.mixtral_moe import QuantMixtralMoE  # noqa: E402
+
+
+def timed(fn, iters=10):
+    for _ in range(2):
+        fn()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(iters):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        fn()
+        e1.record()
+        torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1))
+    return sorted(ts)[len(ts) // 2]
+
+
+def main():
+    moe = QuantMixtralMoE(4096, 14336, 8, 2, "awq", 128, "cuda", seed=0)
+    res = []
+    for tokens in (256, 1024, 4096):
+        x = torch.randn((tokens, 4096), device="cuda").half()
+        with torch.inference_mode():
+            r = timed(lambda: moe.forward_routed(x))
+            d = timed(lambda: moe.forward_dense(x))
+        res.append({"tokens": tokens, "routed_ms": round(r, 3), "dense_loop_ms": round(d, 3)})
+    print(json.dumps(res))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,110 @@
+"""Quantized Mixtral sparse-MoE block on the int4 GEMM, with routed-token execution.
+
+Mirrors MixtralMoE / MixtralMLP of the reference's quantized Mixtral
+(vllm/model_executor/models/mixtral_quant.py:53-156): fp16 router, softmax in fp32, top-k,
+renormalisation, experts split across tensor-parallel ranks (np.array_split), one all-reduce at
+the end.  Two things differ in execution, not in values:
+
+* The reference runs EVERY local expert over ALL tokens and multiplies by a weight that is zero
+  for the tokens not routed there (:141-151).  Here each expert only sees its routed tokens
+  (gather -> w13 GEMM -> SiLU*mul -> w2 GEMM -> weighted scatter-add), 1/4 of the GEMM work at
+  top-2 of 8.  Adding the skipped zero contributions would not change any element, and the
+  per-token accumulation order (ascending expert index) is the reference's.
+* w1 and w3 are stored side by side as one [hidden, 2*ffn] int4 matrix so that one GEMM feeds the
+  fused SiLU*mul kernel (the reference's TODO at :82).
+"""
+from typing import List, Optional
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from vllm_legacy_amd.distributed.communication_op import tensor_model_parallel_all_reduce
+from vllm_legacy_amd.distributed.parallel_state import (get_tensor_model_parallel_rank,
+                                                        get_tensor_model_parallel_world_size)
+from vllm_legacy_amd.layers import SiluAndMul
+from vllm_legacy_amd.model.llama_decode import QuantLinear
+
+
+class QuantMixtralMLP(nn.Module):
+
+    def __init__(self, hidden_size: int, intermediate_size: int, quant: str, group_size: int,
+                 device, generator, dtype=torch.float16):
+        super().__init__()
+        self.w13 = QuantLinear(hidden_size, 2 * intermediate_size, quant, group_size, device,
+                               generator, dtype)
+        self.w2 = QuantLinear(intermediate_size, hidden_size, quant, group_size, device, generator,
+                              dtype)
+        self.act_fn = SiluAndMul()
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return self.w2(self.act_fn(self.w13(x)))
+
+
+class QuantMixtralMoE(nn.Module):
+
+    def __init__(self, hidden_size: int, intermediate_size: int, num_experts: int = 8,
+                 top_k: int = 2, quant: str = "awq", group_size: int = 128, device="cuda",
+                 seed: int = 0, dtype=torch.float16):
+        super().__init__()
+        self.rank = get_tensor_model_parallel_rank()
+        self.tp_size = get_tensor_model_parallel_world_size()
+        self.num_total_experts, self.top_k = num_experts, top_k
+        if self.tp_size > num_experts:
+            raise ValueError(f"Tensor parallel size {self.tp_size} is greater than the number of "
+                             f"experts {num_experts}.")
+        self.expert_indicies: List[int] = np.array_split(range(num_experts),
+                                                         self.tp_size)[self.rank].tolist()
+        g = torch.Generator(device=device).manual_seed(seed)
+        gate = torch.empty(hidden_size, num_experts, dtype=dtype, device=device)
+        gate.normal_(0, 0.05, generator=g)
+        self.gate = nn.Parameter(gate, requires_grad=False)
+        # every rank draws all experts' weights in the same order so that an expert has the same
+        # weights wherever it lives; only the local ones are kept
+        experts: List[Optional[nn.Module]] = []
+        for idx in range(num_experts):
+            e = QuantMixtralMLP(hidden_size, intermediate_size, quant, group_size, device, g, dtype)
+            experts.append(e if idx in self.expert_indicies else None)
+        self.experts = nn.ModuleList([e if e is not None else nn.Identity() for e in experts])
+
+    def route(self, hidden_states: torch.Tensor):
+        router_logits = torch.matmul(hidden_states, self.gate)
+        routing_weights = torch.softmax(router_logits, dim=1, dtype=torch.float)
+        routing_weights, selected_experts = torch.topk(routing_weights, self.top_k, dim=-1)
+        routing_weights /= routing_weights.sum(dim=-1, keepdim=True)
+        return routing_weights, selected_experts
+
+    # below this many tokens every expert's weights are the cost and a 128-row GEMM tile is not
+    # full either way: the dense loop (no host synchronisation, graph-capturable) is used
+    ROUTED_MIN_TOKENS = 512
+
+    def forward(self, hidden_states: torch.Tensor) -> torch.Tensor:
+        if hidden_states.shape[0] < self.ROUTED_MIN_TOKENS:
+            return self.forward_dense(hidden_states)
+        return self.forward_routed(hidden_states)
+
+    def forward_routed(self, hidden_states: torch.Tensor) -> torch.Tensor:
+        num_tokens, hidden_dim = hidden_states.shape
+        routing_weights, selected_experts = self.route(hidden_states)
+        final = torch.zeros_like(hidden_states)
+        for expert_idx in self.expert_indicies:
+            mask = selected_experts == expert_idx                       # [T, top_k]
+            tok = mask.any(dim=-1).nonzero(as_tuple=True)[0]            # routed tokens, ascending
+            if tok.numel() == 0:
+                continue
+            w = (routing_weights * mask).sum(dim=-1, keepdim=True)[tok]  # fp32 [n, 1]
+            out = self.experts[expert_idx](hidden_states[tok])
+            out.mul_(w)                                                 # fp32 product, fp16 store
+            final.index_add_(0, tok, out)
+        return tensor_model_parallel_all_reduce(final).view(num_tokens, hidden_dim)
+
+    def forward_dense(self, hidden_states: torch.Tensor) -> torch.Tensor:
+        """The reference's execution order (every expert over every token), for comparison."""
+        routing_weights, selected_experts = self.route(hidden_states)
+        final = None
+        for expert_idx in self.expert_indicies:
+            mask = selected_experts == expert_idx
+            w = (routing_weights * mask).sum(dim=-1, keepdim=True)
+            cur = self.experts[expert_idx](hidden_states).mul_(w)
+            final = cur if final is None else final.add_(cur)
+        return tensor_model_parallel_all_reduce(final)
