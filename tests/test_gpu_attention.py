@@ -201,9 +201,9 @@ def test_errors_match_reference_messages(ops):
     with pytest.raises(RuntimeError, match="Unsupported head size"):
         ops.paged_attention_v1(torch.empty_like(q72), q72, c.t_kc, c.t_vc, 8, c.scale, c.t_bt,
                                c.t_sl, 16, 40, None, "auto", 1.0)
-    with pytest.raises(RuntimeError, match="[Bb]locksparse"):
+    with pytest.raises(RuntimeError, match="[Bb]locksparse"):   # sparse block size must be positive
         ops.paged_attention_v1(out, c.t_q, c.t_kc, c.t_vc, 8, c.scale, c.t_bt, c.t_sl, 16, 40,
-                               None, "auto", 1.0, 0, 16, 8, 64, 0)
+                               None, "auto", 1.0, 0, 16, 8, 0, 0)
 
 
 # ---------------------------------------------------------------- full-size properties

@@ -29,10 +29,15 @@ def main():
     ap.add_argument("--layers", type=int, default=2)
     ap.add_argument("--version", default="v1")
     ap.add_argument("--ragged", action="store_true", help="sequence lengths U(1, seq)")
+    ap.add_argument("--block", type=int, default=16)
+    ap.add_argument("--head-size", type=int, default=128)
+    ap.add_argument("--generic", action="store_true", help="force the coverage kernel")
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
     dt = torch.float16 if a.dtype == "f16" else torch.bfloat16
-    B, S, BS, D = a.batch, a.seq, 16, 128
+    B, S, BS, D = a.batch, a.seq, a.block, a.head_size
+    if a.generic:
+        ops.set_attention_path(1)
     nb = B * (S // BS)
     g = torch.Generator(device=dev).manual_seed(0)
     scale = D**-0.5
@@ -89,7 +94,7 @@ def main():
     tokens = int(sl.sum().item())
     algo = 2 * a.hkv * D * tokens * e_kv + 4 * B * (S // BS) + 2 * B * a.hq * D * 2 + 8 * B
     med = ts[len(ts) // 2]
-    print(json.dumps({"version": a.version, "kv": a.kv, "batch": B, "seq": S, "ragged": a.ragged,
+    print(json.dumps({"version": a.version, "kv": a.kv, "block": BS, "head_size": D, "generic": a.generic, "batch": B, "seq": S, "ragged": a.ragged,
                       "ms_median": round(med, 4), "ms_min": round(ts[0], 4), "ms_mean": round(sum(ts) / len(ts), 4),
                       "algo_bytes": algo, "GBps_median": round(algo / med / 1e6, 1),
                       "frac_of_8TBps": round(algo / med / 1e6 / 8000, 4)}))

@@ -42,7 +42,6 @@ namespace {
 
 constexpr int kThreads = 256;
 constexpr int kWaves = 4;
-constexpr int kBS = 16;  // KV block size handled here
 
 template <class S>
 __device__ __forceinline__ f32x4 mfma16(u32x4 a, u32x4 b, f32x4 c);
@@ -89,20 +88,23 @@ __device__ __forceinline__ u32x4 mask_tokens(u32x4 v, int nvalid) {
   return v;
 }
 
-template <class S, bool FP8, int D, bool PARTITIONED>
+// D: head size (a multiple of 16; the q.K contraction is padded with zero query dims up to the
+// next multiple of 4 K chunks), BS: KV block size (16 or 32).
+template <class S, bool FP8, int D, int BS, bool PARTITIONED>
 __global__ __launch_bounds__(kThreads, 2) void pa_mfma_kernel(AttnParams p, int heads_per_wg) {
   using T = typename S::T;
+  constexpr int kBS = BS;
   constexpr int X = FP8 ? 16 : 8;          // elements per 16-byte K chunk
   constexpr int TG = FP8 ? 16 : 8;         // tokens per 16-byte V load
   constexpr int STEP = 4 * TG;             // tokens per wave step
   constexpr int NT = STEP / 16;            // q.K tiles (16 tokens each) per step
-  constexpr int KL = D / (4 * X);          // K loads per tile per lane
-  constexpr int KS = D / 32;               // MFMA k-steps per q.K tile
+  constexpr int KL = (D + 4 * X - 1) / (4 * X);  // K loads per tile per lane
+  constexpr int KS = FP8 ? 2 * KL : KL;    // MFMA k-steps per q.K tile
   constexpr int ND = D / 16;               // head-dim tiles of the output
   constexpr int PM = FP8 ? 2 : 1;          // MFMAs fed by one V load
   constexpr int CE = FP8 ? 1 : 2;          // cache element bytes
   constexpr int P_PITCH = STEP * 2 + 16;   // bytes per head row of the probability tile
-  static_assert(KL * 4 * X == D && KS * 32 == D, "head size must be a multiple of 64 (fp8) / 32");
+  static_assert(D % 16 == 0 && (BS == 16 || BS == 32), "head size multiple of 16, block 16 or 32");
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -133,7 +135,9 @@ __global__ __launch_bounds__(kThreads, 2) void pa_mfma_kernel(AttnParams p, int 
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
       const int d0 = FP8 ? 16 * (g + 4 * (ks >> 1)) + 8 * (ks & 1) : 8 * (g + 4 * ks);
-      qf[ks] = (c < nheads) ? *reinterpret_cast<const u32x4*>(q + d0) : u32x4{0, 0, 0, 0};
+      // dims past the head (padding of the contraction) and heads this workgroup does not own
+      qf[ks] = (c < nheads && d0 < D) ? *reinterpret_cast<const u32x4*>(q + d0)
+                                       : u32x4{0, 0, 0, 0};
     }
   }
   const float alibi = (p.alibi_slopes && c < nheads) ? p.alibi_slopes[head_base + c] : 0.f;
@@ -144,9 +148,16 @@ __global__ __launch_bounds__(kThreads, 2) void pa_mfma_kernel(AttnParams p, int 
   const unsigned char* vbase = reinterpret_cast<const unsigned char*>(p.v_cache) +
                                (int64_t)kv_head * p.kv_head_stride * CE;
   const int64_t blk_bytes = p.kv_block_stride * CE;
-  // per-lane byte offsets inside a block
-  const int k_lane_off = (g * kBS + c) * 16;  // chunk g (+4j), token c
-  const int v_lane_off = FP8 ? c * kBS : (c * kBS + 8 * (g & 1)) * 2;
+  // per-lane byte offsets inside a block; a 16-token tile t starts at token (16 t) % BS of its
+  // block, and a lane's V load covers tile g (fp8: 16 tokens) or half of tile g >> 1 (8 tokens)
+  const int k_lane_off = (g * kBS + c) * 16;  // chunk g (+4j), token c (+ tile offset)
+  const int v_tok_off = FP8 ? (16 * g) % kBS : (16 * (g >> 1)) % kBS + 8 * (g & 1);
+  const int v_lane_off = (c * kBS + v_tok_off) * CE;
+  // K chunk g + 4j lies past the head for the last j of some lanes: those lanes re-read chunk g
+  // (finite data) against zero query dims
+  int k_j_off[KL];
+#pragma unroll
+  for (int j = 0; j < KL; ++j) k_j_off[j] = ((g + 4 * j) * X < D) ? j * (4 * kBS * 16) : 0;
 
   f32x4 o[ND];
 #pragma unroll
@@ -159,15 +170,16 @@ __global__ __launch_bounds__(kThreads, 2) void pa_mfma_kernel(AttnParams p, int 
   auto step_blocks = [&](int step, int (&blk)[NT]) {
     const int b0 = (tok_begin + step * STEP) / kBS;
 #pragma unroll
-    for (int t = 0; t < NT; ++t) blk[t] = bt[min(b0 + t, last_blk)];
+    for (int t = 0; t < NT; ++t) blk[t] = bt[min(b0 + (16 * t) / kBS, last_blk)];
   };
   auto load_k = [&](const int (&blk)[NT], u32x4 (&kb)[NT * KL]) {
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-      const unsigned char* kp = kbase + (int64_t)blk[t] * blk_bytes + k_lane_off;
+      const unsigned char* kp = kbase + (int64_t)blk[t] * blk_bytes + k_lane_off +
+                                ((16 * t) % kBS) * 16;
 #pragma unroll
       for (int j = 0; j < KL; ++j)
-        kb[t * KL + j] = *reinterpret_cast<const u32x4*>(kp + j * (4 * kBS * 16));
+        kb[t * KL + j] = *reinterpret_cast<const u32x4*>(kp + k_j_off[j]);
     }
   };
 
@@ -344,8 +356,8 @@ __global__ __launch_bounds__(kThreads, 2) void pa_mfma_kernel(AttnParams p, int 
   }
 }
 
-template <class S, bool FP8, int D>
-int launch_t(const AttnParams& p, hipStream_t s) {
+template <class S, bool FP8, int D, int BS>
+int launch_b(const AttnParams& p, hipStream_t s) {
   const int qpk = p.num_heads / p.num_kv_heads;
   // query heads per workgroup: the whole GQA group when it fits the 16 rows of a tile
   int hpw = qpk <= 16 ? qpk : 16;
@@ -358,23 +370,28 @@ int launch_t(const AttnParams& p, hipStream_t s) {
   dim3 grid(p.num_kv_heads * groups_per_kv, p.num_seqs,
             p.max_num_partitions > 0 ? p.max_num_partitions : 1);
   if (p.max_num_partitions > 0)
-    hipLaunchKernelGGL((pa_mfma_kernel<S, FP8, D, true>), grid, dim3(kThreads), smem, s, p, hpw);
+    hipLaunchKernelGGL((pa_mfma_kernel<S, FP8, D, BS, true>), grid, dim3(kThreads), smem, s, p, hpw);
   else
-    hipLaunchKernelGGL((pa_mfma_kernel<S, FP8, D, false>), grid, dim3(kThreads), smem, s, p, hpw);
+    hipLaunchKernelGGL((pa_mfma_kernel<S, FP8, D, BS, false>), grid, dim3(kThreads), smem, s, p, hpw);
   VLA_HIP_CHECK(hipGetLastError());
   return VLA_OK;
+}
+
+template <class S, bool FP8, int D>
+int launch_t(const AttnParams& p, hipStream_t s) {
+  return p.block_size == 16 ? launch_b<S, FP8, D, 16>(p, s) : launch_b<S, FP8, D, 32>(p, s);
 }
 
 template <class S, bool FP8>
 int launch_d(const AttnParams& p, hipStream_t s) {
   switch (p.head_size) {
     case 64: return launch_t<S, FP8, 64>(p, s);
+    case 80: return launch_t<S, FP8, 80>(p, s);
+    case 96: return launch_t<S, FP8, 96>(p, s);
+    case 112: return launch_t<S, FP8, 112>(p, s);
     case 128: return launch_t<S, FP8, 128>(p, s);
     case 192: return launch_t<S, FP8, 192>(p, s);
     case 256: return launch_t<S, FP8, 256>(p, s);
-    case 96:
-      if constexpr (!FP8) return launch_t<S, false, 96>(p, s);
-      return -1;
     default: return -1;
   }
 }
@@ -382,7 +399,7 @@ int launch_d(const AttnParams& p, hipStream_t s) {
 }  // namespace
 
 int launch_paged_attention_mfma(const AttnParams& p, int dtype, int kv_dtype, hipStream_t s) {
-  if (p.block_size != kBS) return -1;
+  if (p.block_size != 16 && p.block_size != 32) return -1;
   if (dtype != VLA_F16 && dtype != VLA_BF16) return -1;
   const bool fp8 = kv_dtype == VLA_KV_FP8_E4M3;
   const int ce = fp8 ? 1 : 2;
