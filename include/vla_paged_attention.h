@@ -209,13 +209,35 @@ int vla_silu_and_mul(void* out, const void* input, int num_tokens, int d, int dt
  * (vllm/attention/backends/rocm_flash_attn.py:305-383).  query/out [T, num_heads, head_size],
  * key/value [T, num_kv_heads, head_size], row strides in elements; cu_seqlens [num_seqs + 1]
  * int32 on the device (the reference's seq_start_loc); alibi_slopes [num_heads] f32 or NULL
- * (bias slope * (j - i)).  fp16 / bf16, head_size 64 or 128; other shapes: VLA_ERR_HEAD_SIZE /
- * VLA_ERR_DTYPE (the caller keeps its previous path for those). */
+ * (bias slope * (j - i)).  fp16 / bf16, head_size 64/80/96/112/128; other shapes:
+ * VLA_ERR_HEAD_SIZE / VLA_ERR_DTYPE (the caller keeps its previous path for those). */
 int vla_prefill_attention(void* out, const void* query, const void* key, const void* value,
                           const int* cu_seqlens, int num_seqs, int max_seqlen, int num_heads,
                           int num_kv_heads, int head_size, int64_t query_stride,
                           int64_t key_stride, int64_t value_stride, int64_t out_stride,
                           float scale, const float* alibi_slopes, int dtype, void* stream);
+
+/* Replaces context_attention_fwd (vllm/attention/ops/prefix_prefill.py:684-830, the Triton
+ * kernels :10-230 and :443-680) as called by PagedAttention.forward_prefix
+ * (vllm/attention/ops/paged_attn.py:185-216): the new tokens of sequence s (rows
+ * query_start_loc[s] .. of query/key/value/out) attend the context_lens[s] tokens already in the
+ * paged cache (block_tables[s], layouts as for paged_attention) and, causally, each other;
+ * seq_lens[s] = context_lens[s] + number of new tokens.  All index arrays int32 on the device.
+ * alibi_slopes as above with absolute positions; sliding_window > 0 keeps keys less than that
+ * many positions behind the query (0 / negative: off).  kv_cache_dtype/kv_scale as for
+ * paged_attention: a byte cache is decoded with the codec that wrote it.  fp16 / bf16,
+ * head_size 64/80/96/112/128, block_size 16/32/64 (and 8 for a 16-bit cache). */
+int vla_prefix_prefill_attention(void* out, const void* query, const void* key, const void* value,
+                                 const void* key_cache, const void* value_cache,
+                                 const int* block_tables, int max_blocks_per_seq,
+                                 const int* query_start_loc, const int* seq_lens,
+                                 const int* context_lens, int num_seqs, int max_query_len,
+                                 int num_heads, int num_kv_heads, int head_size, int block_size,
+                                 int64_t query_stride, int64_t key_stride, int64_t value_stride,
+                                 int64_t out_stride, int64_t kv_block_stride,
+                                 int64_t kv_head_stride, float scale, const float* alibi_slopes,
+                                 int sliding_window, int dtype, int kv_cache_dtype, float kv_scale,
+                                 void* stream);
 
 /* ---- fused forms (same results as the separate calls, fewer launches) ----------------------- */
 

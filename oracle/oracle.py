@@ -215,6 +215,34 @@ def prefill_attention(q, k, v, seq_lens, scale, dt, alibi_slopes=None):
     return out
 
 
+def prefix_prefill_attention(q, k, v, key_cache, value_cache, block_tables, query_lens, ctx_lens,
+                             scale, dt, kv=KV_AUTO, kv_scale=1.0, alibi_slopes=None,
+                             sliding_window=0):
+    """q [T, Hq, D], k/v [T, Hkv, D]: the new tokens of every sequence, packed; key_cache
+    [NB, Hkv, D/x, BS, x] and value_cache [NB, Hkv, D, BS] hold the ctx_lens[s] earlier tokens of
+    sequence s at block_tables[s].  Returns out [T, Hq, D]."""
+    T_, Hq, D = q.shape
+    Hkv = k.shape[1]
+    NB, _, _, BS, x = key_cache.shape
+    assert value_cache.shape == (NB, Hkv, D, BS)
+    qs = np.zeros(len(query_lens) + 1, dtype=np.int32)
+    qs[1:] = np.cumsum(query_lens)
+    assert qs[-1] == T_
+    ctx = np.ascontiguousarray(ctx_lens, dtype=np.int32)
+    sl = (ctx + np.asarray(query_lens, dtype=np.int32)).astype(np.int32)
+    bt = np.ascontiguousarray(block_tables, dtype=np.int32)
+    out = np.zeros_like(q)
+    al = None if alibi_slopes is None else np.ascontiguousarray(alibi_slopes, dtype=np.float32)
+    lib().oracle_prefix_prefill_attention(
+        _p(out), _p(_c(q)), _p(_c(k)), _p(_c(v)), _p(_c(key_cache)), _p(_c(value_cache)), _p(bt),
+        C.c_int(bt.shape[1]), _p(qs), _p(sl), _p(ctx), C.c_int(len(query_lens)), C.c_int(Hq),
+        C.c_int(Hkv), C.c_int(D), C.c_int(BS), C.c_int(x), C.c_int64(Hq * D), C.c_int64(Hkv * D),
+        C.c_int64(Hkv * D), C.c_int64(Hq * D), C.c_int64(Hkv * D * BS), C.c_int64(D * BS),
+        C.c_float(scale), _p(al), C.c_int(sliding_window), C.c_int(dt), C.c_int(kv),
+        C.c_float(kv_scale))
+    return out
+
+
 # ------------------------------------------------------------------ int4 weights
 
 

@@ -522,6 +522,86 @@ void oracle_prefill_attention(void* out, const void* q, const void* k, const voi
   }
 }
 
+/* Prompt attention over a cached prefix: the new tokens of sequence s attend the ctx_lens[s]
+ * tokens already in the paged cache and, causally, each other
+ * (vllm/attention/ops/prefix_prefill.py:54-230 and :443-680; called from
+ * vllm/attention/ops/paged_attn.py:185-216).  Key j of the sequence (absolute position) is read
+ * from the cache when j < ctx and from k/v row query_start_loc[s] + j - ctx otherwise; query i
+ * sits at position ctx + i.  ALiBi adds slope * (j - (ctx + i)) (:524-565, :608-638); a sliding
+ * window W > 0 keeps keys with (ctx + i) - j < W (:130-147, :199-203; its -10000 substitute is a
+ * zero weight whenever the diagonal key is live, which it always is).
+ * The reference kernel bitcasts a byte cache to e5m2 without a scale (:119-120, :169-170) although
+ * reshape_and_cache wrote e4m3 / kv_scale; this restatement decodes with the codec that wrote the
+ * cache (load_cache above), which is what the decode kernels do.
+ * Probabilities are normalised, then rounded to the value dtype before the value product (:166-172). */
+void oracle_prefix_prefill_attention(void* out, const void* q, const void* k, const void* v,
+                                     const void* k_cache, const void* v_cache,
+                                     const int* block_tables, int max_blocks_per_seq,
+                                     const int* query_start_loc, const int* seq_lens,
+                                     const int* ctx_lens, int num_seqs, int num_heads,
+                                     int num_kv_heads, int head_size, int block_size, int x,
+                                     int64_t q_stride, int64_t k_stride, int64_t v_stride,
+                                     int64_t out_stride, int64_t kv_block_stride,
+                                     int64_t kv_head_stride, float scale, const float* alibi_slopes,
+                                     int sliding_window, int dt, int kv, float kv_scale) {
+  int qpk = num_heads / num_kv_heads;
+#pragma omp parallel for collapse(2) schedule(dynamic, 1)
+  for (int s = 0; s < num_seqs; ++s) {
+    for (int h = 0; h < num_heads; ++h) {
+      int start = query_start_loc[s], ctx = ctx_lens[s], n = seq_lens[s] - ctx;
+      int total = ctx + n;
+      float* logits = (float*)malloc(sizeof(float) * (size_t)(total + 1));
+      float* acc = (float*)malloc(sizeof(float) * (size_t)head_size);
+      float* kd = (float*)malloc(sizeof(float) * (size_t)(total + 1) * head_size);
+      float* vd = (float*)malloc(sizeof(float) * (size_t)(total + 1) * head_size);
+      int kvh = h / qpk;
+      const int* bt = block_tables + (int64_t)s * max_blocks_per_seq;
+      for (int j = 0; j < total; ++j)
+        for (int d = 0; d < head_size; ++d) {
+          if (j < ctx) {
+            int64_t base = (int64_t)bt[j / block_size] * kv_block_stride + (int64_t)kvh * kv_head_stride;
+            int off = j % block_size;
+            kd[(int64_t)j * head_size + d] = load_cache(
+                k_cache, base + (int64_t)(d / x) * block_size * x + (int64_t)off * x + d % x, dt, kv, kv_scale);
+            vd[(int64_t)j * head_size + d] = load_cache(
+                v_cache, base + (int64_t)d * block_size + off, dt, kv, kv_scale);
+          } else {
+            kd[(int64_t)j * head_size + d] =
+                load_scalar(k, (int64_t)(start + j - ctx) * k_stride + (int64_t)kvh * head_size + d, dt);
+            vd[(int64_t)j * head_size + d] =
+                load_scalar(v, (int64_t)(start + j - ctx) * v_stride + (int64_t)kvh * head_size + d, dt);
+          }
+        }
+      for (int i = 0; i < n; ++i) {
+        int qpos = ctx + i;
+        int j0 = sliding_window > 0 && qpos - sliding_window + 1 > 0 ? qpos - sliding_window + 1 : 0;
+        float mx = -3.402823466e+38f;
+        for (int j = j0; j <= qpos; ++j) {
+          float dot = 0.f;
+          for (int d = 0; d < head_size; ++d)
+            dot += load_scalar(q, (int64_t)(start + i) * q_stride + (int64_t)h * head_size + d, dt) *
+                   kd[(int64_t)j * head_size + d];
+          float xx = scale * dot;
+          if (alibi_slopes) xx += alibi_slopes[h] * (float)(j - qpos);
+          logits[j] = xx;
+          mx = fmaxf(mx, xx);
+        }
+        float sum = 0.f;
+        for (int j = j0; j <= qpos; ++j) { logits[j] = expf(logits[j] - mx); sum += logits[j]; }
+        for (int d = 0; d < head_size; ++d) acc[d] = 0.f;
+        for (int j = j0; j <= qpos; ++j) {
+          float pj = round_scalar(logits[j] / sum, dt);
+          for (int d = 0; d < head_size; ++d) acc[d] += pj * vd[(int64_t)j * head_size + d];
+        }
+        for (int d = 0; d < head_size; ++d)
+          store_scalar(out, (int64_t)(start + i) * out_stride + (int64_t)h * head_size + d, dt,
+                       acc[d]);
+      }
+      free(logits); free(acc); free(kd); free(vd);
+    }
+  }
+}
+
 /* ------------------------------------------------------- int4 weight quantisation */
 
 /* AWQ: W[k, 8j + i] = (nib(qweight[k, j], P[i]) - nib(qzeros[k/G, j], P[i])) * scales[k/G, 8j+i]

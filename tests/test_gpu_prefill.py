@@ -53,13 +53,19 @@ def test_prefill_matches_oracle(ops, dt, d, heads, alibi):
     _run(ops, [1, 17, 64, 129, 300, 5], heads[0], heads[1], d, dt, alibi, seed=d + heads[1])
 
 
+@pytest.mark.parametrize("dt", [O.DT_F16, O.DT_BF16])
+@pytest.mark.parametrize("d", [80, 96, 112])
+def test_prefill_other_head_sizes(ops, dt, d):
+    _run(ops, [1, 17, 64, 129, 300, 5], 4, 2, d, dt, False, seed=d)
+
+
 @pytest.mark.parametrize("seq_lens", [[128], [127, 129], [63, 64, 65], [1, 1, 1], [513]])
 def test_prefill_tile_boundaries(ops, seq_lens):
     _run(ops, seq_lens, 4, 2, 128, O.DT_F16, False, seed=len(seq_lens), strided=True)
 
 
 def test_prefill_rejects_unsupported(ops):
-    q = torch.zeros((4, 2, 80), dtype=torch.float16, device="cuda")
+    q = torch.zeros((4, 2, 72), dtype=torch.float16, device="cuda")
     cu = torch.tensor([0, 4], dtype=torch.int32, device="cuda")
     with pytest.raises(RuntimeError, match="head size"):
         ops.prefill_attention(torch.empty_like(q), q, q, q, cu, 4, 1.0)

@@ -46,6 +46,31 @@ def main():
         ms2 = timed(sdpa, iters=3)
         res[f"{nseq}x{s}"] = {"hip_ms": round(ms, 3), "hip_TFLOPs": round(flops / ms / 1e9, 1),
                               "sdpa_ms": round(ms2, 3), "sdpa_TFLOPs": round(flops / ms2 / 1e9, 1)}
+    # prompt continuing a cached prefix: `s` new tokens after `ctx` cached ones
+    bs = 16
+    for nseq, ctx, s, kvd in ((8, 3072, 1024, "auto"), (8, 3072, 1024, "fp8"), (32, 4032, 64, "fp8"),
+                              (4, 0, 8192, "auto")):
+        t = nseq * s
+        qkv = torch.empty((t, (hq + 2 * hkv) * d), dtype=torch.float16, device=dev).uniform_(-1, 1)
+        q, k, v = [x.view(t, -1, d) for x in qkv.split([hq * d, hkv * d, hkv * d], dim=-1)]
+        out = torch.empty((t, hq, d), dtype=torch.float16, device=dev)
+        mb = max(1, (ctx + bs - 1) // bs)
+        nb = nseq * mb
+        if kvd == "fp8":
+            kc = torch.randint(0, 120, (nb, hkv, d // 16, bs, 16), dtype=torch.uint8, device=dev)
+            vc = torch.randint(0, 120, (nb, hkv, d, bs), dtype=torch.uint8, device=dev)
+        else:
+            kc = torch.empty((nb, hkv, d // 8, bs, 8), dtype=torch.float16, device=dev).uniform_(-1, 1)
+            vc = torch.empty((nb, hkv, d, bs), dtype=torch.float16, device=dev).uniform_(-1, 1)
+        bt = torch.randperm(nb, device=dev).to(torch.int32).view(nseq, mb)
+        qs = torch.arange(0, t + 1, s, dtype=torch.int32, device=dev)
+        sl = torch.full((nseq,), ctx + s, dtype=torch.int32, device=dev)
+        cl = torch.full((nseq,), ctx, dtype=torch.int32, device=dev)
+        ms = timed(lambda: ops.prefix_prefill_attention(out, q, k, v, kc, vc, bt, qs, sl, cl, s, d**-0.5,
+                                                        None, None, kvd, 1.0))
+        flops = 4.0 * nseq * hq * d * (s * ctx + s * (s + 1) / 2)
+        res[f"prefix {nseq}x({ctx}+{s}) {kvd}"] = {"hip_ms": round(ms, 3),
+                                                   "hip_TFLOPs": round(flops / ms / 1e9, 1)}
     print(json.dumps(res))
 
 

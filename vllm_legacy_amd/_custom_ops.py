@@ -228,7 +228,53 @@ def prefill_attention(out: torch.Tensor, query: torch.Tensor, key: torch.Tensor,
 
 
 def prefill_attention_supported(dtype: torch.dtype, head_size: int) -> bool:
-    return dtype in (torch.float16, torch.bfloat16) and head_size in (64, 128)
+    return dtype in (torch.float16, torch.bfloat16) and head_size in (64, 80, 96, 112, 128)
+
+
+def prefix_prefill_attention(out: torch.Tensor, query: torch.Tensor, key: torch.Tensor,
+                             value: torch.Tensor, key_cache: torch.Tensor,
+                             value_cache: torch.Tensor, block_tables: torch.Tensor,
+                             query_start_loc: torch.Tensor, seq_lens: torch.Tensor,
+                             context_lens: torch.Tensor, max_query_len: int, scale: float,
+                             alibi_slopes: Optional[torch.Tensor] = None,
+                             sliding_window: Optional[int] = None,
+                             kv_cache_dtype: str = "auto", kv_scale: float = 1.0) -> None:
+    """Prompt attention over a cached prefix (the reference's context_attention_fwd,
+    vllm/attention/ops/prefix_prefill.py:684-744): query/out [T, Hq, D] and key/value
+    [T, Hkv, D] hold the new tokens of every sequence, packed at query_start_loc [B + 1];
+    key_cache [NB, Hkv, D/x, BS, x] / value_cache [NB, Hkv, D, BS] hold the context_lens [B]
+    earlier tokens at block_tables [B, max_blocks]; seq_lens [B] = context + new.  The index
+    tensors are int32 on the device."""
+    _require_cuda(out, query, key, value, key_cache, value_cache, block_tables, query_start_loc,
+                  seq_lens, context_lens, alibi_slopes)
+    for x in (block_tables, query_start_loc, seq_lens, context_lens):
+        assert x.dtype == torch.int32 and x.is_contiguous()
+    t, hq, d = query.shape
+    hkv = key.shape[1]
+    for x in (out, query, key, value):
+        assert x.stride(2) == 1 and x.stride(1) == d
+    assert key_cache.is_contiguous() and value_cache.is_contiguous()
+    nb, hkv_c, d_c, bs = value_cache.shape
+    assert hkv_c == hkv and d_c == d and key_cache.shape[3] == bs
+    num_seqs = seq_lens.numel()
+    assert query_start_loc.numel() >= num_seqs + 1 and context_lens.numel() == num_seqs
+    with torch.cuda.device(query.device):
+        check(_lib.lib().vla_prefix_prefill_attention(
+            out.data_ptr(), query.data_ptr(), key.data_ptr(), value.data_ptr(),
+            key_cache.data_ptr(), value_cache.data_ptr(), block_tables.data_ptr(),
+            block_tables.stride(0), query_start_loc.data_ptr(), seq_lens.data_ptr(),
+            context_lens.data_ptr(), num_seqs, max_query_len, hq, hkv, d, bs, query.stride(0),
+            key.stride(0), value.stride(0), out.stride(0), value_cache.stride(0),
+            value_cache.stride(1), scale, _ptr(alibi_slopes),
+            int(sliding_window) if sliding_window else 0, _dt(query),
+            _lib.kv_dtype_code(kv_cache_dtype), kv_scale, _stream(query.device)),
+            "prefix_prefill_attention")
+
+
+def prefix_prefill_supported(dtype: torch.dtype, head_size: int, block_size: int,
+                             kv_cache_dtype: str = "auto") -> bool:
+    sizes = (16, 32, 64) if kv_cache_dtype != "auto" else (8, 16, 32, 64)
+    return prefill_attention_supported(dtype, head_size) and block_size in sizes
 
 
 # ---------------------------------------------------------------- cache ops

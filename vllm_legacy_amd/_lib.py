@@ -27,7 +27,7 @@ EXPORTS = [
     "vla_gptq_shuffle", "vla_get_max_shared_memory_per_block", "vla_awq_repack",
     "vla_q4_gemm_workspace_bytes", "vla_q4_gemm_packed", "vla_rms_norm",
     "vla_fused_add_rms_norm", "vla_rotary_embedding", "vla_silu_and_mul",
-    "vla_prefill_attention", "vla_q4_gemm_packed_partial", "vla_rotary_reshape_and_cache", "vla_fused_add_rms_norm_splitk",
+    "vla_prefill_attention", "vla_prefix_prefill_attention", "vla_q4_gemm_packed_partial", "vla_rotary_reshape_and_cache", "vla_fused_add_rms_norm_splitk",
 ]
 
 
@@ -77,6 +77,9 @@ def lib():
         L.vla_silu_and_mul.argtypes = [p, p, i, i, i, p]
         L.vla_prefill_attention.argtypes = [p, p, p, p, p, i, i, i, i, i, i64, i64, i64, i64, f, p,
                                             i, p]
+        L.vla_prefix_prefill_attention.argtypes = [p, p, p, p, p, p, p, i, p, p, p, i, i, i, i, i, i,
+                                                   i64, i64, i64, i64, i64, i64, f, p, i, i, i, f,
+                                                   p]
         L.vla_q4_gemm_packed_partial.argtypes = [p, p, p, p, p, i, i, i, i, i, p, i64, p, p]
         L.vla_rotary_reshape_and_cache.argtypes = [p, p, p, p, p, p, p, p, i, i, i, i, i, i64, i64,
                                                    i64, i, i, i, i, i, f, p, i, i64, i64, i, i, i,

@@ -148,7 +148,24 @@ class Gfx950PagedAttentionImpl(AttentionImpl):
 
         prefill_meta = attn_metadata.prefill_metadata
         if prefill_meta is not None:
-            if ops.prefill_attention_supported(query.dtype, self.head_size):
+            bt = prefill_meta.block_tables
+            if kv_cache is not None and bt is not None and bt.numel() > 0:
+                # prefix-enabled attention (rocm_flash_attn.py:368-383): the prompt continues
+                # tokens that are already in the cache
+                block_size = value_cache.shape[3]
+                if not ops.prefix_prefill_supported(query.dtype, self.head_size, block_size,
+                                                    self.kv_cache_dtype):
+                    raise NotImplementedError(
+                        f"prefix prefill: dtype {query.dtype}, head size {self.head_size}, "
+                        f"block size {block_size} has no gfx950 kernel")
+                output[:n_pre] = PagedAttention.forward_prefix(
+                    query[:n_pre], key[:n_pre], value[:n_pre], key_cache, value_cache,
+                    bt.to(torch.int32), prefill_meta.query_start_loc.to(torch.int32),
+                    prefill_meta.seq_lens_tensor.to(torch.int32),
+                    prefill_meta.context_lens_tensor.to(torch.int32),
+                    int(prefill_meta.max_query_len), self._alibi(query.device), None,
+                    self.kv_cache_dtype, kv_scale, self.scale)
+            elif ops.prefill_attention_supported(query.dtype, self.head_size):
                 # HIP flash-style kernel over the packed prompt tokens; seq_start_loc is the
                 # cumulative prompt length table the reference's metadata carries
                 # (rocm_flash_attn.py:84-88)

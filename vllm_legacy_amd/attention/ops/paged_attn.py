@@ -88,6 +88,27 @@ class PagedAttention:
         return output
 
     @staticmethod
+    def forward_prefix(query: torch.Tensor, key: torch.Tensor, value: torch.Tensor,
+                       key_cache: torch.Tensor, value_cache: torch.Tensor,
+                       block_tables: torch.Tensor, query_start_loc: torch.Tensor,
+                       seq_lens_tensor: torch.Tensor, context_lens: torch.Tensor,
+                       max_query_len: int, alibi_slopes: Optional[torch.Tensor],
+                       sliding_window: Optional[int], kv_cache_dtype: str = "auto",
+                       kv_scale: float = 1.0, scale: Optional[float] = None) -> torch.Tensor:
+        """Prompt attention over a cached prefix (vllm/attention/ops/paged_attn.py:185-216).
+        The reference's kernel fixes the softmax scale at head_size ** -0.5
+        (vllm/attention/ops/prefix_prefill.py:707) and reads a byte cache without its scale;
+        `scale`, `kv_cache_dtype` and `kv_scale` let the caller pass the layer's own values."""
+        output = torch.empty_like(query)
+        head_size = query.shape[-1]
+        ops.prefix_prefill_attention(
+            output, query, key, value, key_cache, value_cache, block_tables, query_start_loc,
+            seq_lens_tensor, context_lens, max_query_len,
+            head_size ** -0.5 if scale is None else scale, alibi_slopes, sliding_window,
+            kv_cache_dtype, kv_scale)
+        return output
+
+    @staticmethod
     def swap_blocks(src_kv_cache, dst_kv_cache, src_to_dst: torch.Tensor) -> None:
         ops.swap_blocks(src_kv_cache[0], dst_kv_cache[0], src_to_dst)
         ops.swap_blocks(src_kv_cache[1], dst_kv_cache[1], src_to_dst)

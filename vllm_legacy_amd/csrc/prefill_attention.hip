@@ -55,38 +55,93 @@ struct PrefillParams {
   const void* q;
   const void* k;
   const void* v;
-  const int* cu_seqlens;
+  const int* cu_seqlens;          // [num_seqs + 1] start of each sequence's new tokens
   const float* alibi_slopes;
   int num_heads, num_kv_heads;
   int64_t q_stride, k_stride, v_stride, out_stride;
   float scale;
+  int sliding_window;             // 0 = off
+  // cached prefix (PREFIX kernels only)
+  const void* k_cache;
+  const void* v_cache;
+  const int* block_tables;
+  const int* seq_lens;            // [num_seqs] cached + new tokens
+  const int* ctx_lens;            // [num_seqs] cached tokens
+  int max_blocks_per_seq;
+  int log2_block_size;
+  int64_t kv_block_stride, kv_head_stride;
+  float kv_scale;
 };
 
-// 16-byte chunk swizzles of the LDS images (row = key, RB bytes per row):
-//   K image, read by ds_read_b128 with rows on lanes: 256-byte rows chunk ^ (row & 15);
-//            128-byte rows chunk ^ (row & 7) (the row parity picks the half of the bank row)
-//   V image, read by ds_read_b64_tr_b16 (8 keys x 32 bytes per half wave): 256-byte rows
-//            chunk ^ (((row & 3) << 2) | ((row >> 2) & 3)); 128-byte rows
+// 16-byte chunk swizzles of the LDS images (RB bytes per row):
+//   K image (row = key) and the transposed V image of cached blocks (row = dim), read by
+//            ds_read_b128 with rows on lanes: 256-byte rows chunk ^ (row & 15); 128-byte rows
+//            chunk ^ (row & 7) (the row parity picks the half of the bank row)
+//   V image (row = key), read by ds_read_b64_tr_b16 (8 keys x 32 bytes per half wave): 256-byte
+//            rows chunk ^ (((row & 3) << 2) | ((row >> 2) & 3)); 128-byte rows
 //            chunk ^ ((((row >> 1) & 1) << 1) | (((row >> 3) & 1) << 2))
-template <int D>
+template <int DP>
 __device__ __forceinline__ int k_swz(int row, int ch) {
-  return D == 128 ? (ch ^ (row & 15)) : (ch ^ (row & 7));
+  return DP == 128 ? (ch ^ (row & 15)) : (ch ^ (row & 7));
 }
-template <int D>
+template <int DP>
 __device__ __forceinline__ int v_swz(int row, int ch) {
-  return D == 128 ? (ch ^ (((row & 3) << 2) | ((row >> 2) & 3)))
-                  : (ch ^ ((((row >> 1) & 1) << 1) | (((row >> 3) & 1) << 2)));
+  return DP == 128 ? (ch ^ (((row & 3) << 2) | ((row >> 2) & 3)))
+                   : (ch ^ ((((row >> 1) & 1) << 1) | (((row >> 3) & 1) << 2)));
 }
 
-template <class S, int D>
-__global__ __launch_bounds__(PF_THREADS, 2) void prefill_attention_kernel(PrefillParams p) {
+// 16 fp8 bytes -> 16 model-dtype values (two 16-byte chunks).  scale == 1 takes the exact
+// hardware conversion; otherwise round(float(fp8) * scale) per element, as the decode kernels'
+// reference does (csrc/quantization/fp8/amd/quant_utils.cuh:310-318).
+template <class S>
+__device__ __forceinline__ void pf_fp8x16(const u32x4 w, float scale, u32x4& lo, u32x4& hi) {
+  uint32_t r[8];
+  if (scale == 1.0f) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const u32x2 t = fp8x4_to_16<S>(w[i]);
+      r[2 * i] = t[0];
+      r[2 * i + 1] = t[1];
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const f32x2 a = fp8x2_to_f32<false>(w[i]), b = fp8x2_to_f32<true>(w[i]);
+      r[2 * i] = pf_pack2<S>(a[0] * scale, a[1] * scale);
+      r[2 * i + 1] = pf_pack2<S>(b[0] * scale, b[1] * scale);
+    }
+  }
+  lo = u32x4{r[0], r[1], r[2], r[3]};
+  hi = u32x4{r[4], r[5], r[6], r[7]};
+}
+
+// keep the first `live` (0..8) 16-bit elements of a chunk, zero the rest
+__device__ __forceinline__ u32x4 pf_keep_first(u32x4 w, int live) {
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const uint32_t m = (2 * e < live ? 0xffffu : 0u) | (2 * e + 1 < live ? 0xffff0000u : 0u);
+    w[e] &= m;
+  }
+  return w;
+}
+
+// D: head size (a multiple of 16, at most 128; 112 needs the registers of a whole SIMD lane
+// budget, so it runs one workgroup per CU); the LDS images are laid out for DP = 64 or 128
+// dims per row, the query fragments and the K image zero-padded up to a multiple of 32 dims.
+// PREFIX: keys [0, ctx) of a sequence come from the paged cache (FP8: as e4m3 bytes).
+template <class S, int D, bool PREFIX, bool FP8>
+__global__ __launch_bounds__(PF_THREADS, D == 112 ? 1 : 2) void prefill_attention_kernel(PrefillParams p) {
   using T = typename S::T;
-  constexpr int RB = D * 2;                 // bytes per K/V row in LDS
-  constexpr int CH = D / 8;                 // 16-byte chunks per row
-  constexpr int KS = D / 32;                // MFMA k-steps of the S^T product
+  constexpr int DP = D <= 64 ? 64 : 128;
+  constexpr int RB = DP * 2;                // bytes per K/V row in LDS
+  constexpr int CH = D / 8;                 // live 16-byte chunks per row
+  constexpr int KS = (D + 31) / 32;         // MFMA k-steps of the S^T product
   constexpr int ND = D / 16;                // output dim tiles
-  constexpr int LD = (PF_BN * CH) / PF_THREADS;  // 16-byte loads per thread and tile (K or V)
+  constexpr int LD = (PF_BN * CH + PF_THREADS - 1) / PF_THREADS;  // 16-byte loads per thread, tile
+  constexpr bool LD_EXACT = (PF_BN * CH) % PF_THREADS == 0;
   constexpr int P_PITCH = PF_BN * 2 + 16;   // bytes per query row of the probability tile
+  static_assert(D % 16 == 0 && D <= 128 && D >= 16, "head size");
+  static_assert(PF_BN * RB >= D * PF_BN * 2, "transposed V image fits");
   __shared__ __attribute__((aligned(16))) unsigned char k_lds[PF_BN * RB];
   __shared__ __attribute__((aligned(16))) unsigned char v_lds[PF_BN * RB];
   __shared__ __attribute__((aligned(16))) unsigned char p_all[4 * 32 * P_PITCH];
@@ -97,9 +152,12 @@ __global__ __launch_bounds__(PF_THREADS, 2) void prefill_attention_kernel(Prefil
   const int head = blockIdx.y, seq = blockIdx.z;
   const int kv_head = head / (p.num_heads / p.num_kv_heads);
   const int seq_start = p.cu_seqlens[seq];
-  const int seq_len = p.cu_seqlens[seq + 1] - seq_start;
+  const int ctx = PREFIX ? p.ctx_lens[seq] : 0;
+  // number of new tokens; positions are absolute: query i sits at ctx + i
+  const int n_new = PREFIX ? p.seq_lens[seq] - ctx : p.cu_seqlens[seq + 1] - seq_start;
   const int q0 = blockIdx.x * PF_BM;
-  if (q0 >= seq_len) return;
+  if (q0 >= n_new) return;
+  const int W = p.sliding_window;
   unsigned char* p_lds = p_all + wave * (32 * P_PITCH);
 
   const T* qb = reinterpret_cast<const T*>(p.q) + (int64_t)seq_start * p.q_stride + (int64_t)head * D;
@@ -108,18 +166,31 @@ __global__ __launch_bounds__(PF_THREADS, 2) void prefill_attention_kernel(Prefil
 
   // ---- query fragments; rows past the sequence are clamped (their results are never stored)
   u32x4 qf[2][KS];
-  int qrow[2];
+  int qpos[2];
 #pragma unroll
   for (int sub = 0; sub < 2; ++sub) {
-    qrow[sub] = q0 + 32 * wave + 16 * sub + c;
-    const T* qp = qb + (int64_t)min(qrow[sub], seq_len - 1) * p.q_stride;
+    const int qrow = q0 + 32 * wave + 16 * sub + c;
+    qpos[sub] = ctx + qrow;
+    const T* qp = qb + (int64_t)min(qrow, n_new - 1) * p.q_stride;
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks)
-      qf[sub][ks] = *reinterpret_cast<const u32x4*>(qp + 8 * g + 32 * ks);
+    for (int ks = 0; ks < KS; ++ks) {
+      if (D % 32 == 0 || g + 4 * ks < CH)
+        qf[sub][ks] = *reinterpret_cast<const u32x4*>(qp + 8 * g + 32 * ks);
+      else
+        qf[sub][ks] = u32x4{0u, 0u, 0u, 0u};
+    }
+  }
+  if (D % 32 != 0) {
+    // the K image's padding chunks are never written again: clear them (everything) once
+    for (int i = tid; i < PF_BN * RB / 16; i += PF_THREADS)
+      reinterpret_cast<u32x4*>(k_lds)[i] = u32x4{0u, 0u, 0u, 0u};
+    __syncthreads();
   }
   constexpr float kLog2e = 1.4426950408889634f;
   const float scale2 = p.scale * kLog2e;
   const float slope2 = p.alibi_slopes ? p.alibi_slopes[head] * kLog2e : 0.f;
+  // positions of this wave's first and last query
+  const int wq_min = ctx + q0 + 32 * wave, wq_max = wq_min + 31;
 
   f32x4 o[2][ND];
 #pragma unroll
@@ -128,44 +199,125 @@ __global__ __launch_bounds__(PF_THREADS, 2) void prefill_attention_kernel(Prefil
     for (int n = 0; n < ND; ++n) o[sub][n] = f32x4{0.f, 0.f, 0.f, 0.f};
   float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.f, 0.f};
 
-  // causal: keys up to the last query of this tile
-  const int k_end = min(seq_len, q0 + PF_BM);
-  const int ntiles = (k_end + PF_BN - 1) / PF_BN;
-
   u32x4 kreg[LD], vreg[LD];
-  auto load_tile = [&](int kt) {
-#pragma unroll
-    for (int i = 0; i < LD; ++i) {
-      const int id = tid + PF_THREADS * i, row = id / CH, ch = id % CH;
-      const int64_t tok = min(kt * PF_BN + row, seq_len - 1);
-      kreg[i] = *reinterpret_cast<const u32x4*>(kb + tok * p.k_stride + 8 * ch);
-      vreg[i] = *reinterpret_cast<const u32x4*>(vb + tok * p.v_stride + 8 * ch);
-    }
-  };
-  auto store_tile = [&]() {
-#pragma unroll
-    for (int i = 0; i < LD; ++i) {
-      const int id = tid + PF_THREADS * i, row = id / CH, ch = id % CH;
-      *reinterpret_cast<u32x4*>(k_lds + row * RB + 16 * k_swz<D>(row, ch)) = kreg[i];
-      *reinterpret_cast<u32x4*>(v_lds + row * RB + 16 * v_swz<D>(row, ch)) = vreg[i];
-    }
-  };
 
-  for (int kt = 0; kt < ntiles; ++kt) {
+  // ---- key tiles of 64: first the cached prefix [0, ctx) out of the paged cache, then the new
+  // tokens up to the last query of this workgroup (causal).  K blocks are [D/x][BS][x] and V
+  // blocks [D][BS], each contiguous, so consecutive threads take consecutive 16-byte pieces of a
+  // block; cached K lands row-major (row = key) like new keys, cached V as it is stored
+  // (row = dim).
+  const int npre = PREFIX ? (ctx + PF_BN - 1) / PF_BN : 0;
+  const int ntiles = npre + (min(n_new, q0 + PF_BM) + PF_BN - 1) / PF_BN;
+  const int lbs = PREFIX ? p.log2_block_size : 0, BS = 1 << lbs;
+  const int* bt = PREFIX ? p.block_tables + (int64_t)seq * p.max_blocks_per_seq : nullptr;
+  const int last_blk = ctx > 0 ? (ctx - 1) >> lbs : 0;
+  constexpr int EB = FP8 ? 1 : 2;                       // bytes per cached element
+  constexpr int KX = 16 / EB;                           // dims per 16-byte piece of cached K
+  constexpr int NPIECE = PF_BN * D / KX;                // pieces per cached tile (K or V)
+  constexpr int LP = (NPIECE + PF_THREADS - 1) / PF_THREADS;
+  static_assert(LP <= LD, "piece registers");
+  const unsigned char* kcb = nullptr;
+  const unsigned char* vcb = nullptr;
+  if (PREFIX) {
+    kcb = reinterpret_cast<const unsigned char*>(p.k_cache) + (int64_t)kv_head * p.kv_head_stride * EB;
+    vcb = reinterpret_cast<const unsigned char*>(p.v_cache) + (int64_t)kv_head * p.kv_head_stride * EB;
+  }
+  const int tvl = lbs - (FP8 ? 4 : 3);                  // log2(16-byte pieces per V row of a block)
+
+  for (int it = 0; it < ntiles; ++it) {
+    const bool pre = PREFIX && it < npre;               // workgroup-uniform
+    // first key of the tile (absolute position) and the end of the keys it may hold
+    const int kpos0 = pre ? it * PF_BN : ctx + (it - npre) * PF_BN;
+    const int limit = pre ? ctx : ctx + n_new;
+    // the whole tile lies before the window of this workgroup's first query
+    if (W > 0 && ctx + q0 - (kpos0 + PF_BN - 1) >= W) continue;
     // two workgroups share a CU: while this one waits for its tile, the other one computes
-    load_tile(kt);
-    __syncthreads();                 // every wave is done reading the previous tile
-    store_tile();
+    if (pre) {
+#pragma unroll
+      for (int i = 0; i < LP; ++i) {
+        const int id = tid + PF_THREADS * i;
+        if (NPIECE % PF_THREADS == 0 || id < NPIECE) {
+          // K piece: [block in tile][dim group][token in block]
+          const int off = id & (BS - 1), rest = id >> lbs;
+          const int cg = rest % (D / KX), blk = rest / (D / KX);
+          const int64_t nb = bt[min((kpos0 >> lbs) + blk, last_blk)];
+          kreg[i] = *reinterpret_cast<const u32x4*>(kcb + nb * p.kv_block_stride * EB +
+                                                    ((int64_t)(cg * BS + off) * 16));
+          // V piece: [block in tile][dim][token group]
+          const int tg = id & ((1 << tvl) - 1), rest2 = id >> tvl;
+          const int d = rest2 % D, blk2 = rest2 / D;
+          const int64_t nb2 = bt[min((kpos0 >> lbs) + blk2, last_blk)];
+          vreg[i] = *reinterpret_cast<const u32x4*>(vcb + nb2 * p.kv_block_stride * EB +
+                                                    ((int64_t)d * BS * EB + tg * 16));
+        }
+      }
+      __syncthreads();                 // every wave is done reading the previous tile
+#pragma unroll
+      for (int i = 0; i < LP; ++i) {
+        const int id = tid + PF_THREADS * i;
+        if (NPIECE % PF_THREADS == 0 || id < NPIECE) {
+          const int off = id & (BS - 1), rest = id >> lbs;
+          const int cg = rest % (D / KX), blk = rest / (D / KX);
+          const int row = (blk << lbs) + off;
+          const int tg = id & ((1 << tvl) - 1), rest2 = id >> tvl;
+          const int d = rest2 % D, blk2 = rest2 / D;
+          // first key of the V piece and how many of its keys exist
+          const int key0 = (blk2 << lbs) + tg * (16 / EB);
+          const int live = ctx - (kpos0 + key0);
+          unsigned char* vrow = v_lds + d * (PF_BN * 2);
+          if (FP8) {
+            u32x4 lo, hi;
+            pf_fp8x16<S>(kreg[i], p.kv_scale, lo, hi);
+            *reinterpret_cast<u32x4*>(k_lds + row * RB + 16 * k_swz<DP>(row, 2 * cg)) = lo;
+            *reinterpret_cast<u32x4*>(k_lds + row * RB + 16 * k_swz<DP>(row, 2 * cg + 1)) = hi;
+            pf_fp8x16<S>(vreg[i], p.kv_scale, lo, hi);
+            if (live < 16) {
+              lo = pf_keep_first(lo, max(live, 0));
+              hi = pf_keep_first(hi, max(live - 8, 0));
+            }
+            *reinterpret_cast<u32x4*>(vrow + 16 * k_swz<64>(d, key0 >> 3)) = lo;
+            *reinterpret_cast<u32x4*>(vrow + 16 * k_swz<64>(d, (key0 >> 3) + 1)) = hi;
+          } else {
+            *reinterpret_cast<u32x4*>(k_lds + row * RB + 16 * k_swz<DP>(row, cg)) = kreg[i];
+            u32x4 w = vreg[i];
+            // a value past the prefix may be anything, NaN included: its weight is zero, so must it be
+            if (live < 8) w = pf_keep_first(w, max(live, 0));
+            *reinterpret_cast<u32x4*>(vrow + 16 * k_swz<64>(d, key0 >> 3)) = w;
+          }
+        }
+      }
+    } else {
+      const int kt = it - npre;
+#pragma unroll
+      for (int i = 0; i < LD; ++i) {
+        const int id = tid + PF_THREADS * i, row = id / CH, ch = id % CH;
+        if (LD_EXACT || id < PF_BN * CH) {
+          const int64_t tok = min(kt * PF_BN + row, n_new - 1);
+          kreg[i] = *reinterpret_cast<const u32x4*>(kb + tok * p.k_stride + 8 * ch);
+          vreg[i] = *reinterpret_cast<const u32x4*>(vb + tok * p.v_stride + 8 * ch);
+        }
+      }
+      __syncthreads();                 // every wave is done reading the previous tile
+#pragma unroll
+      for (int i = 0; i < LD; ++i) {
+        const int id = tid + PF_THREADS * i, row = id / CH, ch = id % CH;
+        if (LD_EXACT || id < PF_BN * CH) {
+          *reinterpret_cast<u32x4*>(k_lds + row * RB + 16 * k_swz<DP>(row, ch)) = kreg[i];
+          *reinterpret_cast<u32x4*>(v_lds + row * RB + 16 * v_swz<DP>(row, ch)) = vreg[i];
+        }
+      }
+    }
     __syncthreads();
-    const int k0 = kt * PF_BN;
-    // this wave's queries all precede the tile: nothing to add (wave-uniform)
-    if (k0 > q0 + 32 * wave + 31) continue;
+    // wave-uniform: every key follows every query of this wave, or lies before all their windows
+    if (kpos0 > wq_max) continue;
+    if (W > 0 && wq_min - (kpos0 + PF_BN - 1) >= W) continue;
 
     // ---- online softmax of query c (per query tile) over this lane's keys, in base 2: logits
     // are scaled by scale * log2(e) so that every exponential is a bare v_exp_f32.  A tile that
-    // lies entirely below the diagonal of this wave's queries and inside the sequence needs no
-    // mask (wave-uniform test).
-    const bool interior = (k0 + PF_BN - 1 <= q0 + 32 * wave) && (k0 + PF_BN <= seq_len);
+    // lies entirely below the diagonal of this wave's queries, inside the sequence and inside
+    // every window needs no mask (wave-uniform test).
+    const bool interior = (kpos0 + PF_BN - 1 <= wq_min) && (kpos0 + PF_BN <= limit) &&
+                          (W <= 0 || wq_max - kpos0 < W);
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub) {
       // S^T = K q^T for this query tile: 4 key blocks of 16 (the two query tiles go one after the
@@ -178,7 +330,7 @@ __global__ __launch_bounds__(PF_THREADS, 2) void prefill_attention_kernel(Prefil
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
           const u32x4 kf = *reinterpret_cast<const u32x4*>(k_lds + row * RB +
-                                                           16 * k_swz<D>(row, g + 4 * ks));
+                                                           16 * k_swz<DP>(row, g + 4 * ks));
           acc = pf_mfma<S>(kf, qf[sub][ks], acc);
         }
         st[t] = acc;
@@ -188,10 +340,14 @@ __global__ __launch_bounds__(PF_THREADS, 2) void prefill_attention_kernel(Prefil
       for (int t = 0; t < 4; ++t)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          const int key = k0 + 16 * t + 4 * g + i;
+          const int key = kpos0 + 16 * t + 4 * g + i;
           float x = st[t][i] * scale2;
-          if (slope2 != 0.f) x += slope2 * (float)(key - qrow[sub]);
-          if (!interior) x = (key <= qrow[sub] && key < seq_len) ? x : -INFINITY;
+          if (slope2 != 0.f) x += slope2 * (float)(key - qpos[sub]);
+          if (!interior) {
+            bool live = key <= qpos[sub] && key < limit;
+            if (W > 0) live = live && (qpos[sub] - key < W);
+            x = live ? x : -INFINITY;
+          }
           st[t][i] = x;
           mx = fmaxf(mx, x);
         }
@@ -240,16 +396,23 @@ __global__ __launch_bounds__(PF_THREADS, 2) void prefill_attention_kernel(Prefil
       const int r0 = 32 * kk + 8 * g + (c >> 2);   // key row this lane addresses (first 4 keys)
 #pragma unroll
       for (int n = 0; n < ND; ++n) {
-        const int ch = 2 * n + ((c & 3) >> 1), half = (c & 1) * 8;
-        typedef short s16x4 __attribute__((ext_vector_type(4)));
-        typedef s16x4 __attribute__((address_space(3))) * lds_ptr;
-        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-            (lds_ptr)(v_lds + r0 * RB + 16 * v_swz<D>(r0, ch) + half));
-        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-            (lds_ptr)(v_lds + (r0 + 4) * RB + 16 * v_swz<D>(r0 + 4, ch) + half));
         u32x4 vf;
-        const u32x2 lo2 = __builtin_bit_cast(u32x2, lo), hi2 = __builtin_bit_cast(u32x2, hi);
-        vf[0] = lo2[0]; vf[1] = lo2[1]; vf[2] = hi2[0]; vf[3] = hi2[1];
+        if (pre) {
+          // row = dim 16n + c, 128-byte rows of 64 keys: keys 8g + 32kk .. +7 are one chunk
+          const int row = 16 * n + c;
+          vf = *reinterpret_cast<const u32x4*>(v_lds + row * (PF_BN * 2) +
+                                               16 * k_swz<64>(row, g + 4 * kk));
+        } else {
+          const int ch = 2 * n + ((c & 3) >> 1), half = (c & 1) * 8;
+          typedef short s16x4 __attribute__((ext_vector_type(4)));
+          typedef s16x4 __attribute__((address_space(3))) * lds_ptr;
+          const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (lds_ptr)(v_lds + r0 * RB + 16 * v_swz<DP>(r0, ch) + half));
+          const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (lds_ptr)(v_lds + (r0 + 4) * RB + 16 * v_swz<DP>(r0 + 4, ch) + half));
+          const u32x2 lo2 = __builtin_bit_cast(u32x2, lo), hi2 = __builtin_bit_cast(u32x2, hi);
+          vf[0] = lo2[0]; vf[1] = lo2[1]; vf[2] = hi2[0]; vf[3] = hi2[1];
+        }
         o[0][n] = pf_mfma<S>(pf[0], vf, o[0][n]);
         o[1][n] = pf_mfma<S>(pf[1], vf, o[1][n]);
       }
@@ -267,7 +430,7 @@ __global__ __launch_bounds__(PF_THREADS, 2) void prefill_attention_kernel(Prefil
     for (int i = 0; i < 4; ++i) {
       const float li = __shfl(l, 4 * g + i, 64);
       const int row = q0 + 32 * wave + 16 * sub + 4 * g + i;
-      if (row >= seq_len) continue;
+      if (row >= n_new) continue;
       T* op = reinterpret_cast<T*>(p.out) + (int64_t)(seq_start + row) * p.out_stride +
               (int64_t)head * D;
       const float inv = 1.f / li;
@@ -282,6 +445,30 @@ __global__ __launch_bounds__(PF_THREADS, 2) void prefill_attention_kernel(Prefil
 
 using namespace vla;
 
+namespace {
+
+bool pf_head_size_ok(int d) { return d == 64 || d == 80 || d == 96 || d == 112 || d == 128; }
+
+template <bool PREFIX, bool FP8>
+void pf_launch(const PrefillParams& p, int head_size, int dtype, dim3 grid, hipStream_t s) {
+#define VLA_PF(ST, DD)                                                                       \
+  hipLaunchKernelGGL((prefill_attention_kernel<ST, DD, PREFIX, FP8>), grid, dim3(PF_THREADS), \
+                     0, s, p)
+#define VLA_PF_D(ST)                     \
+  switch (head_size) {                   \
+    case 64: VLA_PF(ST, 64); break;      \
+    case 80: VLA_PF(ST, 80); break;      \
+    case 96: VLA_PF(ST, 96); break;      \
+    case 112: VLA_PF(ST, 112); break;    \
+    default: VLA_PF(ST, 128); break;     \
+  }
+  if (dtype == VLA_F16) { VLA_PF_D(F16) } else { VLA_PF_D(BF16) }
+#undef VLA_PF_D
+#undef VLA_PF
+}
+
+}  // namespace
+
 extern "C" int vla_prefill_attention(void* out, const void* query, const void* key,
                                      const void* value, const int* cu_seqlens, int num_seqs,
                                      int max_seqlen, int num_heads, int num_kv_heads, int head_size,
@@ -294,22 +481,62 @@ extern "C" int vla_prefill_attention(void* out, const void* query, const void* k
       num_heads <= 0 || num_kv_heads <= 0 || num_heads % num_kv_heads)
     return VLA_ERR_ARG;
   if (dtype != VLA_F16 && dtype != VLA_BF16) return VLA_ERR_DTYPE;
-  if (head_size != 64 && head_size != 128) return VLA_ERR_HEAD_SIZE;
+  if (!pf_head_size_ok(head_size)) return VLA_ERR_HEAD_SIZE;
   if ((query_stride | key_stride | value_stride | out_stride) % 8 || ((uintptr_t)query % 16) ||
       ((uintptr_t)key % 16) || ((uintptr_t)value % 16))
     return VLA_ERR_ARG;
-  PrefillParams p{out, query, key, value, cu_seqlens, alibi_slopes, num_heads, num_kv_heads,
-                  query_stride, key_stride, value_stride, out_stride, scale};
+  PrefillParams p{};
+  p.out = out; p.q = query; p.k = key; p.v = value;
+  p.cu_seqlens = cu_seqlens; p.alibi_slopes = alibi_slopes;
+  p.num_heads = num_heads; p.num_kv_heads = num_kv_heads;
+  p.q_stride = query_stride; p.k_stride = key_stride; p.v_stride = value_stride;
+  p.out_stride = out_stride; p.scale = scale; p.sliding_window = 0;
   dim3 grid((max_seqlen + PF_BM - 1) / PF_BM, num_heads, num_seqs);
-  hipStream_t s = (hipStream_t)stream;
-#define VLA_PF(ST, DD) \
-  hipLaunchKernelGGL((prefill_attention_kernel<ST, DD>), grid, dim3(PF_THREADS), 0, s, p)
-  if (dtype == VLA_F16) {
-    if (head_size == 128) VLA_PF(F16, 128); else VLA_PF(F16, 64);
-  } else {
-    if (head_size == 128) VLA_PF(BF16, 128); else VLA_PF(BF16, 64);
-  }
-#undef VLA_PF
+  pf_launch<false, false>(p, head_size, dtype, grid, (hipStream_t)stream);
+  VLA_HIP_CHECK(hipGetLastError());
+  return VLA_OK;
+}
+
+extern "C" int vla_prefix_prefill_attention(
+    void* out, const void* query, const void* key, const void* value, const void* key_cache,
+    const void* value_cache, const int* block_tables, int max_blocks_per_seq,
+    const int* query_start_loc, const int* seq_lens, const int* context_lens, int num_seqs,
+    int max_query_len, int num_heads, int num_kv_heads, int head_size, int block_size,
+    int64_t query_stride, int64_t key_stride, int64_t value_stride, int64_t out_stride,
+    int64_t kv_block_stride, int64_t kv_head_stride, float scale, const float* alibi_slopes,
+    int sliding_window, int dtype, int kv_dtype, float kv_scale, void* stream) {
+  (void)hipGetLastError();
+  if (num_seqs == 0 || max_query_len == 0) return VLA_OK;
+  if (!out || !query || !key || !value || !key_cache || !value_cache || !block_tables ||
+      !query_start_loc || !seq_lens || !context_lens || num_seqs < 0 || max_query_len < 0 ||
+      max_blocks_per_seq <= 0 || num_heads <= 0 || num_kv_heads <= 0 || num_heads % num_kv_heads)
+    return VLA_ERR_ARG;
+  if (dtype != VLA_F16 && dtype != VLA_BF16) return VLA_ERR_DTYPE;
+  if (kv_dtype != VLA_KV_AUTO && kv_dtype != VLA_KV_FP8_E4M3) return VLA_ERR_KV_DTYPE;
+  if (!pf_head_size_ok(head_size)) return VLA_ERR_HEAD_SIZE;
+  const bool fp8 = kv_dtype == VLA_KV_FP8_E4M3;
+  // a 64-key tile is a whole number of blocks, and a 16-byte piece of a value row stays in a block
+  if (!(block_size == 16 || block_size == 32 || block_size == 64 || (!fp8 && block_size == 8)))
+    return VLA_ERR_BLOCK_SIZE;
+  const int eb = fp8 ? 1 : 2;
+  if ((query_stride | key_stride | value_stride | out_stride) % 8 || ((uintptr_t)query % 16) ||
+      ((uintptr_t)key % 16) || ((uintptr_t)value % 16) || ((uintptr_t)key_cache % 16) ||
+      ((uintptr_t)value_cache % 16) || (kv_block_stride * eb) % 16 || (kv_head_stride * eb) % 16)
+    return VLA_ERR_ARG;
+  PrefillParams p{};
+  p.out = out; p.q = query; p.k = key; p.v = value;
+  p.cu_seqlens = query_start_loc; p.alibi_slopes = alibi_slopes;
+  p.num_heads = num_heads; p.num_kv_heads = num_kv_heads;
+  p.q_stride = query_stride; p.k_stride = key_stride; p.v_stride = value_stride;
+  p.out_stride = out_stride; p.scale = scale;
+  p.sliding_window = sliding_window > 0 ? sliding_window : 0;
+  p.k_cache = key_cache; p.v_cache = value_cache; p.block_tables = block_tables;
+  p.seq_lens = seq_lens; p.ctx_lens = context_lens; p.max_blocks_per_seq = max_blocks_per_seq;
+  p.log2_block_size = block_size == 8 ? 3 : block_size == 16 ? 4 : block_size == 32 ? 5 : 6;
+  p.kv_block_stride = kv_block_stride; p.kv_head_stride = kv_head_stride; p.kv_scale = kv_scale;
+  dim3 grid((max_query_len + PF_BM - 1) / PF_BM, num_heads, num_seqs);
+  if (fp8) pf_launch<true, true>(p, head_size, dtype, grid, (hipStream_t)stream);
+  else pf_launch<true, false>(p, head_size, dtype, grid, (hipStream_t)stream);
   VLA_HIP_CHECK(hipGetLastError());
   return VLA_OK;
 }
