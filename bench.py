@@ -140,6 +140,79 @@ def cpu_baseline(args):
     }
 
 
+def select_all_reduce(device, world, rank, hidden, tokens, dtype):
+    """Tensor-parallel runs: try the peer-memory all-reduce on this node.  It is used for the
+    timed steps only if set-up succeeds on every rank, its results equal the fp32 rank-order sum
+    of the gathered inputs bit for bit on every rank over repeated calls, no barrier wait timed
+    out, and it is faster than the RCCL call on the decode message; otherwise RCCL stays.
+    VLA_XGMI_ALLREDUCE=0 skips the trial.  Returns a record for the result line."""
+    import torch.distributed as dist
+    from vllm_legacy_amd.distributed import communication_op as co
+    from vllm_legacy_amd.distributed import parallel_state as ps
+    rec = {"impl": "rccl", "xgmi_us": None, "rccl_us": None, "xgmi_verified": False, "note": ""}
+    if os.environ.get("VLA_XGMI_ALLREDUCE", "auto") == "0":
+        rec["note"] = "trial skipped"
+        return rec
+    cpu_group = ps.get_tensor_model_parallel_cpu_group()
+    comm = None
+    try:
+        from vllm_legacy_amd.distributed.xgmi_all_reduce import XgmiAllReduce
+        comm = XgmiAllReduce(cpu_group, device)
+        if comm.disabled:
+            rec["note"] = comm.reason
+            return rec
+        ok = True
+        g = torch.Generator(device=device).manual_seed(1234 + rank)
+        for it in range(24):
+            n = tokens * hidden if it % 3 else 8 * (1 + it)
+            x = torch.empty(n, dtype=dtype, device=device).uniform_(-1, 1, generator=g)
+            parts = co.tensor_model_parallel_all_gather(x.view(1, n), dim=0)      # [world, n]
+            want = torch.zeros(n, dtype=torch.float32, device=device)
+            for r in range(world):
+                want += parts[r].float()
+            got = comm.all_reduce(x)
+            ok = ok and torch.equal(got, want.to(dtype))
+        ok = ok and comm.error_count() == 0
+
+        def timed(fn):
+            x = torch.zeros(tokens * hidden, dtype=dtype, device=device)
+            for _ in range(5):
+                fn(x)
+            torch.cuda.synchronize()
+            dist.barrier(group=cpu_group)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(50):
+                fn(x)
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) * 1000 / 50
+
+        t_x = timed(lambda x: comm.all_reduce(x, out=x))
+        t_r = timed(co.tensor_model_parallel_all_reduce)
+        ok = ok and comm.error_count() == 0
+        # one decision for the whole group: everybody verified, and the slowest rank's times
+        flags = torch.tensor([1.0 if ok else 0.0, -t_x, -t_r], dtype=torch.float64)
+        dist.all_reduce(flags, op=dist.ReduceOp.MIN, group=cpu_group)
+        ok, t_x, t_r = flags[0].item() == 1.0, -flags[1].item(), -flags[2].item()
+        rec.update(xgmi_verified=ok, xgmi_us=round(t_x, 1), rccl_us=round(t_r, 1))
+        if ok and t_x < t_r:
+            ps.set_tp_xgmi_all_reduce(comm)
+            rec["impl"] = "xgmi"
+            comm = None
+        elif not ok:
+            rec["note"] = "results differed or a barrier timed out"
+    except Exception as e:  # noqa: BLE001
+        rec["note"] = f"{type(e).__name__}: {str(e).splitlines()[0] if str(e) else ''}"
+    finally:
+        if comm is not None and not comm.disabled:
+            try:
+                comm.close()
+            except Exception:  # noqa: BLE001
+                pass
+    return rec
+
+
 def main():
     args = parse()
     if os.environ.get("VLA_BENCH_WATCHDOG"):
@@ -179,6 +252,9 @@ def main():
                              dtype=model_dtype)
     num_blocks = B * (S // BS) + 8
     kv_caches = fill_kv_caches(model, num_blocks, BS, args.kv, device)
+    ar_rec = None
+    if world > 1:
+        ar_rec = select_all_reduce(device, world, rank, cfg.hidden_size, B, model_dtype)
 
     g = torch.Generator(device=device).manual_seed(7)
     block_tables = torch.randperm(num_blocks, generator=g, device=device)[:B * (S // BS)]
@@ -205,47 +281,65 @@ def main():
         if world > 1:
             torch.distributed.barrier()
 
-    # ---- optional graph capture (decode is replayed from a graph in the reference too,
-    # vllm/worker/model_runner.py:512-515)
-    use_graph = not args.no_graph and not rehearsal
-    graph = None
-    stream = torch.cuda.Stream(device=device)
-    with torch.cuda.stream(stream):
-        step()  # first call: lazy inits (the AWQ repack, the GPTQ shuffle)
-        torch.cuda.synchronize()
-        if use_graph:
-            try:
-                graph = torch.cuda.CUDAGraph()
-                # with collectives in the step, other threads (the process group's watchdog) make
-                # HIP calls of their own; they must not invalidate this thread's capture
-                mode = "thread_local" if world > 1 else "global"
-                with torch.cuda.graph(graph, stream=stream, capture_error_mode=mode):
-                    step()
-            except Exception as e:  # e.g. a collective that cannot be captured
-                if rank == 0:
-                    print(f"[bench] graph capture failed ({type(e).__name__}: "
-                          f"{str(e).splitlines()[0]}); running eagerly", file=sys.stderr)
-                graph = None
-    if use_graph and graph is None:
-        # a failed capture leaves its stream unusable: drain the device and move to a fresh one
-        try:
-            torch.cuda.synchronize()
-        except Exception:
-            pass
+    def measure():
+        """Capture (when possible), warm up and time args.steps steps; returns (seconds, graph,
+        stream)."""
+        # ---- optional graph capture (decode is replayed from a graph in the reference too,
+        # vllm/worker/model_runner.py:512-515)
+        use_graph = not args.no_graph and not rehearsal
+        graph = None
         stream = torch.cuda.Stream(device=device)
-    with torch.cuda.stream(stream):
-        run = graph.replay if graph is not None else step
-        for _ in range(args.warmup):
-            run()
-        torch.cuda.synchronize()
-        barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            run()
-        torch.cuda.synchronize()
-        barrier()
-        elapsed = time.perf_counter() - t0
+        with torch.cuda.stream(stream):
+            step()  # first call: lazy inits (the AWQ repack, the GPTQ shuffle)
+            torch.cuda.synchronize()
+            if use_graph:
+                try:
+                    graph = torch.cuda.CUDAGraph()
+                    # with collectives in the step, other threads (the process group's watchdog) make
+                    # HIP calls of their own; they must not invalidate this thread's capture
+                    mode = "thread_local" if world > 1 else "global"
+                    with torch.cuda.graph(graph, stream=stream, capture_error_mode=mode):
+                        step()
+                except Exception as e:  # e.g. a collective that cannot be captured
+                    if rank == 0:
+                        print(f"[bench] graph capture failed ({type(e).__name__}: "
+                              f"{str(e).splitlines()[0]}); running eagerly", file=sys.stderr)
+                    graph = None
+        if use_graph and graph is None:
+            # a failed capture leaves its stream unusable: drain the device and move to a fresh one
+            try:
+                torch.cuda.synchronize()
+            except Exception:
+                pass
+            stream = torch.cuda.Stream(device=device)
+        with torch.cuda.stream(stream):
+            run = graph.replay if graph is not None else step
+            for _ in range(args.warmup):
+                run()
+            torch.cuda.synchronize()
+            barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                run()
+            torch.cuda.synchronize()
+            barrier()
+            elapsed = time.perf_counter() - t0
+        return elapsed, graph, stream
+
+    elapsed, graph, stream = measure()
+    if ar_rec is not None and ar_rec["impl"] == "xgmi":
+        # a barrier wait that timed out during the run voids it: measure again on RCCL
+        from vllm_legacy_amd.distributed import parallel_state as ps
+        comm = ps.get_tp_xgmi_all_reduce(device)
+        bad = torch.tensor([comm.error_count()], dtype=torch.int32)
+        torch.distributed.all_reduce(bad, op=torch.distributed.ReduceOp.MAX,
+                                     group=ps.get_tensor_model_parallel_cpu_group())
+        if int(bad.item()) > 0:
+            ps.set_tp_xgmi_all_reduce(None)
+            comm.close()
+            ar_rec.update(impl="rccl", note="barrier timeouts during the xgmi run; re-measured on RCCL")
+            elapsed, graph, stream = measure()
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -320,6 +414,7 @@ def main():
                             f"batch {B}, context {S}, block 16, {args.layers} layers",
                 "parallelism": f"tp{world}",
                 "graph": graph is not None,
+                "all_reduce": ar_rec,
                 "global_batch": B,
                 "seq_len": S,
             },
@@ -348,6 +443,8 @@ def main():
         print(json.dumps(result), flush=True)
     if world > 1:
         torch.distributed.barrier()
+        from vllm_legacy_amd.distributed import parallel_state as ps
+        ps.destroy_model_parallel()
         torch.distributed.destroy_process_group()
 
 

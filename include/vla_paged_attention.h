@@ -239,6 +239,36 @@ int vla_prefix_prefill_attention(void* out, const void* query, const void* key, 
                                  int sliding_window, int dtype, int kv_cache_dtype, float kv_scale,
                                  void* stream);
 
+/* ---- all-reduce over xGMI peer memory ---------------------------------------------------------- */
+
+/* Together these take the place of the reference's custom all-reduce (csrc/custom_all_reduce.cuh,
+ * bound in csrc/pybind.cpp:95-110: init_custom_ar, all_reduce_reg/unreg, dispose, meta_size,
+ * register_buffer, get_graph_buffer_ipc_meta, register_graph_buffers), which is CUDA-only.
+ * One region per rank (uncached device memory: barrier slots + two staging halves of max_bytes)
+ * is exported with vla_ar_export (a 64-byte HIP IPC handle the caller ships to the other
+ * processes) and mapped there with vla_ar_import.  vla_ar_create takes the `world` region
+ * pointers as this process sees them (regions[rank] is its own).  The all-reduce stages the input
+ * itself, so no tensor has to be registered, and it is safe to capture in a graph.  All ranks
+ * must issue the same calls in the same order, one stream per rank; the other ranks' regions must
+ * have been zeroed (vla_ar_alloc_region returns after that) before the first call. */
+int vla_ar_region_bytes(int64_t max_bytes, int64_t* out);
+int vla_ar_alloc_region(int64_t max_bytes, void** region);
+int vla_ar_free_region(void* region);
+int vla_ar_export(void* region, unsigned char* handle64);
+int vla_ar_import(const unsigned char* handle64, void** peer_region);
+int vla_ar_unimport(void* peer_region);
+int vla_ar_create(void** ctx, int rank, int world, void* const* regions, int64_t max_bytes,
+                  int num_blocks);
+int vla_ar_destroy(void* ctx);
+/* out = sum over ranks of in (out == in allowed); numel * element size a multiple of 16 and at
+ * most max_bytes; fp32 accumulation in rank order, so every rank receives the same bits
+ * (custom_all_reduce.cuh:297-356 is the two-shot scheme this follows). */
+int vla_ar_all_reduce(void* ctx, void* out, const void* in, int64_t numel, int dtype,
+                      void* stream);
+/* Synchronous.  A barrier wait that saw no peer within its poll limit gives up so that the kernel
+ * terminates; *out counts those events on this rank (non-zero: results are invalid). */
+int vla_ar_error_count(void* ctx, int* out);
+
 /* ---- fused forms (same results as the separate calls, fewer launches) ----------------------- */
 
 /* vla_q4_gemm_packed without its reduction launch: when the product was split along K,

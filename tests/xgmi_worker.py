@@ -1,0 +1,99 @@
+"""One rank of the peer-memory all-reduce test (started by test_gpu_xgmi_allreduce.py, one
+process per rank, all on cuda:0: HIP IPC maps a region of the same device into another process
+exactly as it maps a peer GPU's, so the handshake, the barrier protocol, the double buffering
+and graph replay are exercised; only the xGMI transport itself is not)."""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from vllm_legacy_amd.distributed.xgmi_all_reduce import XgmiAllReduce  # noqa: E402
+
+
+def rank_input(rank, numel, dtype, call):
+    g = torch.Generator().manual_seed(1000 * call + rank)
+    return torch.empty(numel, dtype=torch.float32).uniform_(-1, 1, generator=g).to(dtype)
+
+
+def expected(world, numel, dtype, call):
+    """fp32 sum in rank order, rounded once: the bits the kernel must produce."""
+    acc = torch.zeros(numel, dtype=torch.float32)
+    for r in range(world):
+        acc += rank_input(r, numel, dtype, call).float()
+    return acc.to(dtype)
+
+
+def main():
+    rank, world, port = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    comm = XgmiAllReduce(dist.group.WORLD, dev, max_size=4 << 20)
+    assert not comm.disabled
+    call = 0
+    # ---- sizes and dtypes, out of place and in place, back to back (double buffering)
+    for dtype in (torch.float16, torch.bfloat16, torch.float32):
+        for numel in (8, 64, 4096 + 8, 256 * 4096, 1000 * 8):
+            for inplace in (False, True):
+                call += 1
+                x = rank_input(rank, numel, dtype, call).to(dev)
+                assert comm.should_custom_ar(x)
+                out = comm.all_reduce(x, out=x if inplace else None)
+                want = expected(world, numel, dtype, call)
+                got = out.cpu()
+                assert torch.equal(got.view(torch.uint8), want.view(torch.uint8)), (
+                    dtype, numel, inplace, got[:8].tolist(), want[:8].tolist())
+    # messages the communicator declines
+    assert comm.custom_all_reduce(torch.zeros(7, dtype=torch.float16, device=dev)) is None
+    assert comm.custom_all_reduce(torch.zeros((5 << 20), dtype=torch.float16, device=dev)) is None
+    # ---- graph capture and replay with fresh inputs: barrier counts advance on the device
+    numel = 256 * 4096
+    xs = [torch.zeros(numel, dtype=torch.float16, device=dev) for _ in range(3)]
+    outs = [torch.empty_like(x) for x in xs]
+    stream = torch.cuda.Stream()
+    with torch.cuda.stream(stream):
+        for x, o in zip(xs, outs):      # warm-up on the side stream
+            comm.all_reduce(x, out=o)
+        call += 3
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=stream):
+            for x, o in zip(xs, outs):
+                comm.all_reduce(x, out=o)
+    for _ in range(4):
+        base = call
+        for i, x in enumerate(xs):
+            x.copy_(rank_input(rank, numel, torch.float16, base + i + 1))
+        call += 3
+        graph.replay()
+        torch.cuda.synchronize()
+        for i, o in enumerate(outs):
+            want = expected(world, numel, torch.float16, base + i + 1)
+            assert torch.equal(o.cpu().view(torch.uint8), want.view(torch.uint8)), ("graph", i)
+    # ---- latency of the decode message (2 MiB), informational
+    x = torch.zeros(numel, dtype=torch.float16, device=dev)
+    for _ in range(5):
+        comm.all_reduce(x, out=x)
+    torch.cuda.synchronize()
+    dist.barrier()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(50):
+        comm.all_reduce(x, out=x)
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1000 / 50
+    errors = comm.error_count()
+    comm.close()
+    print(json.dumps({"rank": rank, "world": world, "ok": errors == 0, "timeouts": errors,
+                      "us_per_2MiB_call_same_gpu": round(us, 1)}), flush=True)
+    dist.destroy_process_group()
+    sys.exit(0 if errors == 0 else 3)
+
+
+if __name__ == "__main__":
+    main()

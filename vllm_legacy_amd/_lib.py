@@ -27,7 +27,9 @@ EXPORTS = [
     "vla_gptq_shuffle", "vla_get_max_shared_memory_per_block", "vla_awq_repack",
     "vla_q4_gemm_workspace_bytes", "vla_q4_gemm_packed", "vla_rms_norm",
     "vla_fused_add_rms_norm", "vla_rotary_embedding", "vla_silu_and_mul",
-    "vla_prefill_attention", "vla_prefix_prefill_attention", "vla_q4_gemm_packed_partial", "vla_rotary_reshape_and_cache", "vla_fused_add_rms_norm_splitk",
+    "vla_prefill_attention", "vla_prefix_prefill_attention", "vla_ar_region_bytes", "vla_ar_alloc_region",
+    "vla_ar_free_region", "vla_ar_export", "vla_ar_import", "vla_ar_unimport", "vla_ar_create", "vla_ar_destroy",
+    "vla_ar_all_reduce", "vla_ar_error_count", "vla_q4_gemm_packed_partial", "vla_rotary_reshape_and_cache", "vla_fused_add_rms_norm_splitk",
 ]
 
 
@@ -80,6 +82,16 @@ def lib():
         L.vla_prefix_prefill_attention.argtypes = [p, p, p, p, p, p, p, i, p, p, p, i, i, i, i, i, i,
                                                    i64, i64, i64, i64, i64, i64, f, p, i, i, i, f,
                                                    p]
+        L.vla_ar_region_bytes.argtypes = [i64, p]
+        L.vla_ar_alloc_region.argtypes = [i64, p]
+        L.vla_ar_free_region.argtypes = [p]
+        L.vla_ar_export.argtypes = [p, p]
+        L.vla_ar_import.argtypes = [p, p]
+        L.vla_ar_unimport.argtypes = [p]
+        L.vla_ar_create.argtypes = [p, i, i, p, i64, i]
+        L.vla_ar_destroy.argtypes = [p]
+        L.vla_ar_all_reduce.argtypes = [p, p, p, i64, i, p]
+        L.vla_ar_error_count.argtypes = [p, p]
         L.vla_q4_gemm_packed_partial.argtypes = [p, p, p, p, p, i, i, i, i, i, p, i64, p, p]
         L.vla_rotary_reshape_and_cache.argtypes = [p, p, p, p, p, p, p, p, i, i, i, i, i, i64, i64,
                                                    i64, i, i, i, i, i, f, p, i, i64, i64, i, i, i,

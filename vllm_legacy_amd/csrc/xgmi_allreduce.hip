@@ -1,0 +1,306 @@
+// SUM all-reduce of a tensor-parallel partial output by direct loads and stores between the
+// GPUs of one xGMI node (no RCCL call on the path).
+//
+// Takes the place of the reference's custom all-reduce (csrc/custom_all_reduce.cuh:180-205
+// barriers, :297-356 two-shot kernel, :442-449 dispatch; wrapper
+// vllm/distributed/device_communicators/custom_all_reduce.py:78-303), which is CUDA-only
+// (custom_all_reduce.py:28-31): on ROCm the reference falls back to RCCL for the 65 small
+// all-reduces of a Llama decode step.
+//
+// Every rank owns one region of uncached device memory, exported over HIP IPC and mapped by
+// all peers:
+//   flags [MAX_BLOCKS][MAX_RANKS] u32   slot [b][p] is written by rank p's block b only
+//   seq   [MAX_BLOCKS] u32              private to the owner: barriers passed so far, per block
+//   err   u32                           private: barriers that gave up waiting
+//   data  2 x max_bytes                 message staging, double buffered by call parity
+// One kernel per call, the same grid on every rank, three steps per block:
+//   1. copy this rank's input into its own staging half;            barrier
+//   2. rank r sums slice r over all ranks' staging halves (fp32, rank order 0..N-1, so the bits
+//      do not depend on who reads them) and writes it back in place; barrier
+//   3. gather every slice from its owner's staging half into `out`.
+// Block b touches the same element set on every rank in every step (a strided walk of each
+// slice), so a barrier only has to pair block b of one rank with block b of the others: each
+// block signals by storing its barrier count into its slot on every peer and waits until its
+// own slots show that count.  The counts live in device memory and advance inside the kernel,
+// so a captured graph replays correctly.  Double buffering makes a closing barrier unnecessary:
+// a rank can only start writing a half again two calls later, and it passes the first barrier
+// of the call in between only after every peer has finished reading in the call before.
+// A wait gives up after a bounded number of polls (the kernel always terminates); the count of
+// such events is kept in `err` and makes results invalid.
+// Calls on one communicator must be issued in the same order with the same sizes by all ranks,
+// on one stream per rank.
+#include "vla_common.h"
+
+#include <string.h>
+
+#include <new>
+
+namespace vla {
+namespace {
+
+constexpr int AR_MAX_RANKS = 8;
+constexpr int AR_MAX_BLOCKS = 96;
+constexpr int AR_THREADS = 512;
+constexpr int64_t AR_FLAG_OFF = 0;
+constexpr int64_t AR_SEQ_OFF = (int64_t)AR_MAX_BLOCKS * AR_MAX_RANKS * 4;
+constexpr int64_t AR_ERR_OFF = AR_SEQ_OFF + AR_MAX_BLOCKS * 4;
+constexpr int64_t AR_DATA_OFF = 4096;
+constexpr unsigned AR_SPIN_LIMIT = 4u * 1000u * 1000u;   // a few seconds of polling
+static_assert(AR_ERR_OFF + 4 <= AR_DATA_OFF, "metadata fits its page");
+
+struct ArParams {
+  unsigned char* region[AR_MAX_RANKS];   // every rank's region as mapped here; [rank] is local
+  int rank, world;
+  int64_t max_bytes;
+};
+
+struct ArContext {
+  ArParams p;
+  int num_blocks;
+  int device;
+};
+
+// All threads of the block have issued the stores the peers are about to read.
+__device__ __forceinline__ void ar_barrier(const ArParams& P, uint32_t count) {
+  __threadfence_system();
+  __syncthreads();
+  const int t = threadIdx.x;
+  if (t < P.world) {
+    uint32_t* theirs = reinterpret_cast<uint32_t*>(P.region[t] + AR_FLAG_OFF) +
+                       (blockIdx.x * AR_MAX_RANKS + P.rank);
+    __hip_atomic_store(theirs, count, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    uint32_t* mine = reinterpret_cast<uint32_t*>(P.region[P.rank] + AR_FLAG_OFF) +
+                     (blockIdx.x * AR_MAX_RANKS + t);
+    unsigned polls = 0;
+    // counts only grow; the signed difference survives a wrap of the counter
+    while ((int32_t)(__hip_atomic_load(mine, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) -
+                     count) < 0) {
+      if (++polls > AR_SPIN_LIMIT) {
+        atomicAdd(reinterpret_cast<uint32_t*>(P.region[P.rank] + AR_ERR_OFF), 1u);
+        break;
+      }
+      __builtin_amdgcn_s_sleep(2);
+    }
+  }
+  __syncthreads();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+}
+
+template <class S>
+__device__ __forceinline__ void ar_accumulate(float (&acc)[8], const u32x4 w) {
+  using T = typename S::T;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const uint16_t lo = (uint16_t)(w[i] & 0xffffu), hi = (uint16_t)(w[i] >> 16);
+    acc[2 * i] += S::to_f32(__builtin_bit_cast(T, lo));
+    acc[2 * i + 1] += S::to_f32(__builtin_bit_cast(T, hi));
+  }
+}
+template <>
+__device__ __forceinline__ void ar_accumulate<F32>(float (&acc)[8], const u32x4 w) {
+  const f32x4 f = __builtin_bit_cast(f32x4, w);
+  acc[0] += f[0];
+  acc[1] += f[1];
+  acc[2] += f[2];
+  acc[3] += f[3];
+}
+
+template <class S>
+__device__ __forceinline__ u32x4 ar_pack(const float (&acc)[8]) {
+  using T = typename S::T;
+  u32x4 w;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const T a = S::from_f32(acc[2 * i]), b = S::from_f32(acc[2 * i + 1]);
+    w[i] = (uint32_t)__builtin_bit_cast(uint16_t, a) |
+           ((uint32_t)__builtin_bit_cast(uint16_t, b) << 16);
+  }
+  return w;
+}
+template <>
+__device__ __forceinline__ u32x4 ar_pack<F32>(const float (&acc)[8]) {
+  const f32x4 f = {acc[0], acc[1], acc[2], acc[3]};
+  return __builtin_bit_cast(u32x4, f);
+}
+
+// dst[i] = src[i] for i = first, first + stride, ... < len, four loads in flight per thread
+__device__ __forceinline__ void ar_copy(u32x4* dst, const u32x4* src, int64_t first, int64_t len,
+                                        int64_t stride) {
+  int64_t i = first;
+  for (; i + 3 * stride < len; i += 4 * stride) {
+    const u32x4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
+    dst[i] = a;
+    dst[i + stride] = b;
+    dst[i + 2 * stride] = c;
+    dst[i + 3 * stride] = d;
+  }
+  for (; i < len; i += stride) dst[i] = src[i];
+}
+
+// nvec: 16-byte units of the message; per: units per slice (the last slice may be short or empty)
+template <class S>
+__global__ __launch_bounds__(AR_THREADS) void xgmi_two_shot_kernel(ArParams P, u32x4* out,
+                                                                   const u32x4* in, int64_t nvec,
+                                                                   int64_t per) {
+  unsigned char* self = P.region[P.rank];
+  uint32_t* seq_slot = reinterpret_cast<uint32_t*>(self + AR_SEQ_OFF) + blockIdx.x;
+  const uint32_t seq = __hip_atomic_load(seq_slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const int64_t half = AR_DATA_OFF + (int64_t)((seq >> 1) & 1u) * P.max_bytes;
+  const int64_t stride = (int64_t)gridDim.x * AR_THREADS;
+  const int64_t first = (int64_t)blockIdx.x * AR_THREADS + threadIdx.x;
+
+  // 1. publish the input
+  u32x4* mine = reinterpret_cast<u32x4*>(self + half);
+  for (int s = 0; s < P.world; ++s) {
+    const int64_t base = s * per, len = min(per, nvec - base);
+    ar_copy(mine + base, in + base, first, len, stride);
+  }
+  ar_barrier(P, seq + 1);
+
+  // 2. reduce this rank's slice in place
+  {
+    const int64_t base = P.rank * per, len = min(per, nvec - base);
+    for (int64_t i = first; i < len; i += stride) {
+      // all ranks' loads in flight together: the link latency is paid once per element
+      u32x4 w[AR_MAX_RANKS];
+#pragma unroll
+      for (int r = 0; r < AR_MAX_RANKS; ++r)
+        if (r < P.world) w[r] = reinterpret_cast<const u32x4*>(P.region[r] + half)[base + i];
+      float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int r = 0; r < AR_MAX_RANKS; ++r)
+        if (r < P.world) ar_accumulate<S>(acc, w[r]);
+      mine[base + i] = ar_pack<S>(acc);
+    }
+  }
+  ar_barrier(P, seq + 2);
+
+  // 3. gather the slices from their owners
+  for (int s = 0; s < P.world; ++s) {
+    const int64_t base = s * per, len = min(per, nvec - base);
+    const u32x4* src = reinterpret_cast<const u32x4*>(P.region[s] + half);
+    ar_copy(out + base, src + base, first, len, stride);
+  }
+  if (threadIdx.x == 0) __hip_atomic_store(seq_slot, seq + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+}  // namespace
+}  // namespace vla
+
+using namespace vla;
+
+extern "C" int vla_ar_region_bytes(int64_t max_bytes, int64_t* out) {
+  if (max_bytes <= 0 || max_bytes % 16 || !out) return VLA_ERR_ARG;
+  *out = AR_DATA_OFF + 2 * max_bytes;
+  return VLA_OK;
+}
+
+extern "C" int vla_ar_alloc_region(int64_t max_bytes, void** region) {
+  int64_t bytes = 0;
+  if (!region || vla_ar_region_bytes(max_bytes, &bytes) != VLA_OK) return VLA_ERR_ARG;
+  void* p = nullptr;
+  VLA_HIP_CHECK(hipExtMallocWithFlags(&p, (size_t)bytes, hipDeviceMallocUncached));
+  hipError_t e = hipMemset(p, 0, (size_t)bytes);
+  if (e == hipSuccess) e = hipDeviceSynchronize();
+  if (e != hipSuccess) {
+    (void)hipFree(p);
+    VLA_HIP_CHECK(e);
+  }
+  *region = p;
+  return VLA_OK;
+}
+
+extern "C" int vla_ar_free_region(void* region) {
+  if (region) VLA_HIP_CHECK(hipFree(region));
+  return VLA_OK;
+}
+
+extern "C" int vla_ar_export(void* region, unsigned char* handle64) {
+  static_assert(sizeof(hipIpcMemHandle_t) == 64, "handle size");
+  if (!region || !handle64) return VLA_ERR_ARG;
+  hipIpcMemHandle_t h;
+  VLA_HIP_CHECK(hipIpcGetMemHandle(&h, region));
+  memcpy(handle64, &h, sizeof(h));
+  return VLA_OK;
+}
+
+extern "C" int vla_ar_import(const unsigned char* handle64, void** peer_region) {
+  if (!handle64 || !peer_region) return VLA_ERR_ARG;
+  hipIpcMemHandle_t h;
+  memcpy(&h, handle64, sizeof(h));
+  void* p = nullptr;
+  VLA_HIP_CHECK(hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess));
+  *peer_region = p;
+  return VLA_OK;
+}
+
+extern "C" int vla_ar_unimport(void* peer_region) {
+  if (peer_region) VLA_HIP_CHECK(hipIpcCloseMemHandle(peer_region));
+  return VLA_OK;
+}
+
+extern "C" int vla_ar_create(void** ctx, int rank, int world, void* const* regions,
+                             int64_t max_bytes, int num_blocks) {
+  if (!ctx || !regions || world < 2 || world > AR_MAX_RANKS || rank < 0 || rank >= world ||
+      max_bytes <= 0 || max_bytes % 16 || num_blocks <= 0 || num_blocks > AR_MAX_BLOCKS)
+    return VLA_ERR_ARG;
+  for (int r = 0; r < world; ++r)
+    if (!regions[r]) return VLA_ERR_ARG;
+  ArContext* c = new (std::nothrow) ArContext();
+  if (!c) return VLA_ERR_ARG;
+  for (int r = 0; r < AR_MAX_RANKS; ++r)
+    c->p.region[r] = r < world ? static_cast<unsigned char*>(regions[r]) : nullptr;
+  c->p.rank = rank;
+  c->p.world = world;
+  c->p.max_bytes = max_bytes;
+  c->num_blocks = num_blocks;
+  hipError_t e = hipGetDevice(&c->device);
+  if (e != hipSuccess) {
+    delete c;
+    VLA_HIP_CHECK(e);
+  }
+  *ctx = c;
+  return VLA_OK;
+}
+
+extern "C" int vla_ar_destroy(void* ctx) {
+  delete static_cast<ArContext*>(ctx);
+  return VLA_OK;
+}
+
+extern "C" int vla_ar_all_reduce(void* ctx, void* out, const void* in, int64_t numel, int dtype,
+                                 void* stream) {
+  (void)hipGetLastError();
+  ArContext* c = static_cast<ArContext*>(ctx);
+  if (!c || !out || !in || numel < 0) return VLA_ERR_ARG;
+  if (dtype != VLA_F16 && dtype != VLA_BF16 && dtype != VLA_F32) return VLA_ERR_DTYPE;
+  const int64_t bytes = numel * (dtype == VLA_F32 ? 4 : 2);
+  if (bytes % 16 || bytes > c->p.max_bytes || ((uintptr_t)out % 16) || ((uintptr_t)in % 16))
+    return VLA_ERR_ARG;
+  const int64_t nvec = bytes / 16;
+  const int64_t per = (nvec + c->p.world - 1) / c->p.world;
+  dim3 grid(c->num_blocks), block(AR_THREADS);
+  hipStream_t s = (hipStream_t)stream;
+  // an empty message still runs the barriers: every rank must pass the same sequence
+  if (dtype == VLA_F16)
+    hipLaunchKernelGGL(xgmi_two_shot_kernel<F16>, grid, block, 0, s, c->p, (u32x4*)out,
+                       (const u32x4*)in, nvec, per);
+  else if (dtype == VLA_BF16)
+    hipLaunchKernelGGL(xgmi_two_shot_kernel<BF16>, grid, block, 0, s, c->p, (u32x4*)out,
+                       (const u32x4*)in, nvec, per);
+  else
+    hipLaunchKernelGGL(xgmi_two_shot_kernel<F32>, grid, block, 0, s, c->p, (u32x4*)out,
+                       (const u32x4*)in, nvec, per);
+  VLA_HIP_CHECK(hipGetLastError());
+  return VLA_OK;
+}
+
+// Synchronous: number of barrier waits that timed out on this rank since the region was made.
+extern "C" int vla_ar_error_count(void* ctx, int* out) {
+  ArContext* c = static_cast<ArContext*>(ctx);
+  if (!c || !out) return VLA_ERR_ARG;
+  uint32_t v = 0;
+  VLA_HIP_CHECK(hipMemcpy(&v, c->p.region[c->p.rank] + AR_ERR_OFF, 4, hipMemcpyDeviceToHost));
+  *out = (int)v;
+  return VLA_OK;
+}

@@ -3,7 +3,8 @@
 Mirrors vllm/distributed/communication_op.py:73-100 (all-reduce), :103-127 (all-gather),
 :130-160 (gather), :227-317 (broadcast_tensor_dict).  On ROCm the reference ends up in
 torch.distributed / RCCL for every one of these (its custom all-reduce is CUDA-only,
-device_communicators/custom_all_reduce.py:28-31); so does this module.  The message of the hot
+device_communicators/custom_all_reduce.py:28-31); so does this module by default, with the
+peer-memory all-reduce of xgmi_all_reduce.py as an opt-in for the hot one.  The message of the hot
 all-reduce is the [tokens, hidden] partial output of a row-parallel linear (2 MiB for
 Llama-3-8B at 256 tokens), issued in place on the compute stream.
 """
@@ -12,7 +13,8 @@ from typing import Any, Dict, Optional
 import torch
 import torch.distributed as dist
 
-from .parallel_state import (get_tensor_model_parallel_cpu_group,
+from .parallel_state import (get_tp_xgmi_all_reduce,
+                             get_tensor_model_parallel_cpu_group,
                              get_tensor_model_parallel_group,
                              get_tensor_model_parallel_rank,
                              get_tensor_model_parallel_src_rank,
@@ -24,6 +26,12 @@ def tensor_model_parallel_all_reduce(input_: torch.Tensor) -> torch.Tensor:
     if get_tensor_model_parallel_world_size() == 1 or not isinstance(input_, torch.Tensor):
         return input_                     # single rank (possibly unreduced split-K slabs)
     group = get_tensor_model_parallel_group()
+    if input_.is_cuda:
+        # opt-in: direct loads/stores over xGMI peer memory instead of an RCCL call
+        # (communication_op.py:87-95 tries the custom all-reduce first in the same way)
+        xgmi = get_tp_xgmi_all_reduce(input_.device)
+        if xgmi is not None and xgmi.should_custom_ar(input_):
+            return xgmi.all_reduce(input_, out=input_)
     if input_.is_cuda and dist.get_backend(group) == "gloo":
         # rehearsal of the GPU code path without RCCL (several ranks on one GPU): stage
         # through the host, where Gloo is at home
@@ -43,9 +51,17 @@ def tensor_model_parallel_all_gather(input_: torch.Tensor, dim: int = -1) -> tor
         dim += input_.dim()
     size = input_.size()
     # flat [world * size0, ...] output: the layout every backend's all_gather_into_tensor accepts
-    out = torch.empty((world * size[0], ) + tuple(size[1:]), dtype=input_.dtype,
-                      device=input_.device)
-    dist.all_gather_into_tensor(out, input_.contiguous(), group=get_tensor_model_parallel_group())
+    group = get_tensor_model_parallel_group()
+    if input_.is_cuda and dist.get_backend(group) == "gloo":
+        # rehearsal without RCCL, see all-reduce above
+        host = input_.contiguous().cpu()
+        out = torch.empty((world * size[0], ) + tuple(size[1:]), dtype=input_.dtype)
+        dist.all_gather_into_tensor(out, host, group=group)
+        out = out.to(input_.device)
+    else:
+        out = torch.empty((world * size[0], ) + tuple(size[1:]), dtype=input_.dtype,
+                          device=input_.device)
+        dist.all_gather_into_tensor(out, input_.contiguous(), group=group)
     out = out.view((world, ) + tuple(size)).movedim(0, dim)
     return out.reshape(size[:dim] + (world * size[dim], ) + size[dim + 1:])
 

@@ -15,6 +15,7 @@ import torch.distributed as dist
 _TP_GROUP: Optional[dist.ProcessGroup] = None
 _TP_CPU_GROUP: Optional[dist.ProcessGroup] = None
 _TP_RANKS = None
+_TP_XGMI = None          # XgmiAllReduce of the TP group, made on first use when enabled
 
 
 def init_distributed_environment(world_size: int = -1, rank: int = -1,
@@ -90,8 +91,33 @@ def get_tensor_model_parallel_src_rank() -> int:
     return _TP_RANKS[0] if _TP_RANKS else 0
 
 
+def get_tp_xgmi_all_reduce(device: torch.device):
+    """The peer-memory all-reduce of the TP group, or None when RCCL is to be used.  Either
+    installed by the caller (set_tp_xgmi_all_reduce, after it has checked and timed it) or, with
+    VLA_XGMI_ALLREDUCE=1, made on first use -- which every rank reaches together (the first
+    all-reduce of a step); the reference builds its custom all-reduce the same lazy way
+    (vllm/distributed/parallel_state.py:170-180 with custom_all_reduce.py:78-130)."""
+    global _TP_XGMI
+    if _TP_XGMI is None and _TP_CPU_GROUP is not None and \
+            os.environ.get("VLA_XGMI_ALLREDUCE", "0") == "1":
+        from .xgmi_all_reduce import XgmiAllReduce
+        _TP_XGMI = XgmiAllReduce(_TP_CPU_GROUP, device)
+        if _TP_XGMI.disabled:
+            raise RuntimeError(f"VLA_XGMI_ALLREDUCE=1 but set-up failed: {_TP_XGMI.reason}")
+    return _TP_XGMI
+
+
+def set_tp_xgmi_all_reduce(comm) -> None:
+    """Install (or with None remove, without closing) the peer-memory all-reduce of the group."""
+    global _TP_XGMI
+    _TP_XGMI = comm
+
+
 def destroy_model_parallel() -> None:
-    global _TP_GROUP, _TP_CPU_GROUP, _TP_RANKS
+    global _TP_GROUP, _TP_CPU_GROUP, _TP_RANKS, _TP_XGMI
+    if _TP_XGMI is not None:
+        _TP_XGMI.close()
+        _TP_XGMI = None
     for g in (_TP_GROUP, _TP_CPU_GROUP):
         if g is not None:
             dist.destroy_process_group(g)
