@@ -246,7 +246,8 @@ int vla_prefix_prefill_attention(void* out, const void* query, const void* key, 
  * register_buffer, get_graph_buffer_ipc_meta, register_graph_buffers), which is CUDA-only.
  * One region per rank (uncached device memory: barrier slots + two staging halves of max_bytes)
  * is exported with vla_ar_export (a 64-byte HIP IPC handle the caller ships to the other
- * processes) and mapped there with vla_ar_import.  vla_ar_create takes the `world` region
+ * processes) and mapped there with vla_ar_import (peer_device: the exporter's device ordinal as
+ * this process numbers devices, for an explicit peer-access check, or -1 if unknown).  vla_ar_create takes the `world` region
  * pointers as this process sees them (regions[rank] is its own).  The all-reduce stages the input
  * itself, so no tensor has to be registered, and it is safe to capture in a graph.  All ranks
  * must issue the same calls in the same order, one stream per rank; the other ranks' regions must
@@ -255,7 +256,7 @@ int vla_ar_region_bytes(int64_t max_bytes, int64_t* out);
 int vla_ar_alloc_region(int64_t max_bytes, void** region);
 int vla_ar_free_region(void* region);
 int vla_ar_export(void* region, unsigned char* handle64);
-int vla_ar_import(const unsigned char* handle64, void** peer_region);
+int vla_ar_import(const unsigned char* handle64, int peer_device, void** peer_region);
 int vla_ar_unimport(void* peer_region);
 int vla_ar_create(void** ctx, int rank, int world, void* const* regions, int64_t max_bytes,
                   int num_blocks);

@@ -86,7 +86,7 @@ def lib():
         L.vla_ar_alloc_region.argtypes = [i64, p]
         L.vla_ar_free_region.argtypes = [p]
         L.vla_ar_export.argtypes = [p, p]
-        L.vla_ar_import.argtypes = [p, p]
+        L.vla_ar_import.argtypes = [p, i, p]
         L.vla_ar_unimport.argtypes = [p]
         L.vla_ar_create.argtypes = [p, i, i, p, i64, i]
         L.vla_ar_destroy.argtypes = [p]

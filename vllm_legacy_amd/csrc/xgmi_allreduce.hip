@@ -224,8 +224,21 @@ extern "C" int vla_ar_export(void* region, unsigned char* handle64) {
   return VLA_OK;
 }
 
-extern "C" int vla_ar_import(const unsigned char* handle64, void** peer_region) {
+extern "C" int vla_ar_import(const unsigned char* handle64, int peer_device, void** peer_region) {
   if (!handle64 || !peer_region) return VLA_ERR_ARG;
+  int cur = 0;
+  VLA_HIP_CHECK(hipGetDevice(&cur));
+  if (peer_device >= 0 && peer_device != cur) {
+    int can = 0;
+    VLA_HIP_CHECK(hipDeviceCanAccessPeer(&can, cur, peer_device));
+    if (!can) {
+      set_last_hip_error((int)hipErrorPeerAccessUnsupported);
+      return VLA_ERR_HIP;
+    }
+    hipError_t e = hipDeviceEnablePeerAccess(peer_device, 0);
+    if (e == hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();
+    else VLA_HIP_CHECK(e);
+  }
   hipIpcMemHandle_t h;
   memcpy(&h, handle64, sizeof(h));
   void* p = nullptr;

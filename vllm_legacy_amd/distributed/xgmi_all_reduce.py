@@ -58,7 +58,11 @@ class XgmiAllReduce:
                 _lib.check(L.vla_ar_export(self._region, handle), "ar_export")
             except Exception as e:  # noqa: BLE001
                 self.reason = f"rank {self.rank}: {e}"
-            handles = self._exchange(bytes(handle))
+            # the device ordinal travels with the handle; it only means something to a peer that
+            # sees the same set of devices
+            index = self.device.index if self.device.index is not None else torch.cuda.current_device()
+            tag = bytes([index & 0xff, torch.cuda.device_count() & 0xff])
+            handles = self._exchange(bytes(handle) + tag)
             if not self.reason:
                 try:
                     regions = (C.c_void_p * self.world_size)()
@@ -68,8 +72,9 @@ class XgmiAllReduce:
                             self._peers.append(None)
                         else:
                             peer = C.c_void_p()
-                            buf = (C.c_ubyte * 64).from_buffer_copy(h)
-                            _lib.check(L.vla_ar_import(buf, C.byref(peer)), "ar_import")
+                            buf = (C.c_ubyte * 64).from_buffer_copy(h[:64])
+                            peer_dev = h[64] if h[65] == torch.cuda.device_count() else -1
+                            _lib.check(L.vla_ar_import(buf, peer_dev, C.byref(peer)), "ar_import")
                             regions[r] = peer.value
                             self._peers.append(peer.value)
                     _lib.check(L.vla_ar_create(C.byref(self._ctx), self.rank, self.world_size,
@@ -89,7 +94,7 @@ class XgmiAllReduce:
         """All-gather of the IPC handles as byte tensors (object collectives misbehave under
         inference mode with Gloo, custom_all_reduce.py:232-236)."""
         t = torch.frombuffer(bytearray(mine), dtype=torch.uint8).clone()
-        out = [torch.empty(64, dtype=torch.uint8) for _ in range(self.world_size)]
+        out = [torch.empty(len(mine), dtype=torch.uint8) for _ in range(self.world_size)]
         dist.all_gather(out, t, group=self.group)
         return [bytes(o.numpy().tobytes()) for o in out]
 
