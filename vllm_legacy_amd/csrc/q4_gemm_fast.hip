@@ -200,16 +200,20 @@ __global__ __launch_bounds__(kThreadsG, 2) void q4_gemm_fast_kernel(
 // Requires group_size % 64 == 0.
 // LDS x image: row r (128 bytes = 8 chunks of 16), chunk q stored at slot q ^ ((r >> 1) & 7):
 // with rows on lanes this keeps every ds_read_b128 lane group on 16 distinct 16-byte slots.
-constexpr int TM2 = 128;
-constexpr int X2_TILE_BYTES = TM2 * TK * 2;  // 16 KiB per buffer
+// MT = 32-row tiles per workgroup: 4 for the batch the kernel is built around; 1 and 2 for small
+// batches, where the work is reading the weights once (HBM-bound) and a 128-row tile would spend
+// MFMA passes and x traffic on rows that do not exist.
 
-template <int ZOFF, bool SPLIT, int NW>
+template <int ZOFF, bool SPLIT, int NW, int MT>
 __global__ __launch_bounds__(64 * NW) void q4_gemm_m32_kernel(
     const _Float16* __restrict__ x, const uint32_t* __restrict__ qw,
     const uint32_t* __restrict__ qz, const _Float16* __restrict__ scales, void* __restrict__ outp,
     int m, int n, int k, int group_size, int k_per_split) {
   constexpr int THREADS = 64 * NW;
-  constexpr int XCH = (TM2 * 8) / THREADS;  // 16-byte chunks of the x tile per thread
+  constexpr int TMW = 32 * MT;                   // rows per workgroup
+  constexpr int X2_TILE_BYTES = TMW * TK * 2;    // one LDS buffer: 16 KiB at MT = 4
+  static_assert((TMW * 8) % THREADS == 0, "x staging covers the tile in whole passes");
+  constexpr int XCH = (TMW * 8) / THREADS;  // 16-byte chunks of the x tile per thread
   constexpr int XROWS = THREADS / 8;        // rows covered by one pass of the staging threads
   __shared__ __attribute__((aligned(16))) unsigned char xs[2 * X2_TILE_BYTES];
 
@@ -217,7 +221,7 @@ __global__ __launch_bounds__(64 * NW) void q4_gemm_m32_kernel(
   const int lane = tid & 63;
   const int wn = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int h = lane >> 5, c = lane & 31;
-  const int n0 = blockIdx.x * (32 * NW), m0 = blockIdx.y * TM2;
+  const int n0 = blockIdx.x * (32 * NW), m0 = blockIdx.y * TMW;
   const int k_begin = blockIdx.z * k_per_split;
   const int k_end = min(k, k_begin + k_per_split);
   const int nsteps = (k_end - k_begin) / TK;
@@ -268,9 +272,9 @@ __global__ __launch_bounds__(64 * NW) void q4_gemm_m32_kernel(
     d.s = ssrc[(int64_t)grp * (n >> 1)];
   };
 
-  f32x16 acc[4];
+  f32x16 acc[MT];
 #pragma unroll
-  for (int a = 0; a < 4; ++a)
+  for (int a = 0; a < MT; ++a)
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[a][i] = 0.f;
 
@@ -293,9 +297,9 @@ __global__ __launch_bounds__(64 * NW) void q4_gemm_m32_kernel(
     const f16x2 sc2 = as_h2(__builtin_amdgcn_perm(wcur.s, wcur.s, ssel));
 
     const unsigned char* xb = xs + buf * X2_TILE_BYTES;
-    auto read_a = [&](int s, u32x4 (&af)[4]) {
+    auto read_a = [&](int s, u32x4 (&af)[MT]) {
 #pragma unroll
-      for (int a = 0; a < 4; ++a) {
+      for (int a = 0; a < MT; ++a) {
         const int row = 32 * a + c;
         af[a] = *reinterpret_cast<const u32x4*>(
             xb + row * 128 + (((2 * s + h) ^ ((row >> 1) & 7)) << 4));
@@ -316,16 +320,16 @@ __global__ __launch_bounds__(64 * NW) void q4_gemm_m32_kernel(
       bf[3] = as_u32(d3 * sc2);
       return bf;
     };
-    auto mma = [&](const u32x4 (&af)[4], const u32x4& bf) {
+    auto mma = [&](const u32x4 (&af)[MT], const u32x4& bf) {
 #pragma unroll
-      for (int a = 0; a < 4; ++a)
+      for (int a = 0; a < MT; ++a)
         acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[a]),
                                                         __builtin_bit_cast(f16x8, bf), acc[a], 0,
                                                         0, 0);
     };
     // fragments of slice s+1 are requested before the MFMAs of slice s are issued
 #define VLA_SB __builtin_amdgcn_sched_barrier(0)
-    u32x4 fa[4], fb[4];
+    u32x4 fa[MT], fb[MT];
     read_a(0, fa);
     u32x4 b0 = dequant(0);
     VLA_SB;
@@ -374,7 +378,7 @@ __global__ __launch_bounds__(64 * NW) void q4_gemm_m32_kernel(
   // ---- epilogue: lane (h, c) holds column ncol, rows (i & 3) + 8 (i >> 2) + 4 h of each 32-row tile
   if (!nok) return;
 #pragma unroll
-  for (int a = 0; a < 4; ++a)
+  for (int a = 0; a < MT; ++a)
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const int row = m0 + 32 * a + (i & 3) + 8 * (i >> 2) + 4 * h;
@@ -452,20 +456,33 @@ using namespace vla;
 //    the slabs and their reduction exceeds what the shorter loop saves (K = 1024, N = 4096:
 //    1 slice 15.3 us, 4 slices 19.2 us).
 // VLA_Q4_TUNE="nw,splits" overrides both (kernel studies).
-struct Q4Shape { int nw, splits; };
+struct Q4Shape { int nw, splits, mt; };
 
 static Q4Shape pick_shape(int m, int n, int k, int group) {
-  const int mt = (m + TM2 - 1) / TM2;
   Q4Shape s;
-  s.nw = (n < 3072 || k <= 2048) ? 4 : 8;
-  const int wgs = ((n + 32 * s.nw - 1) / (32 * s.nw)) * mt;
-  int want = 256 / wgs;
-  if (want > 8) want = 8;
-  if (want > k / (8 * TK)) want = k / (8 * TK);
+  // Small batches (one or two 32-row tiles): the kernel streams the weights once, so the grid is
+  // sized for bytes in flight -- 128-column workgroups and K slices until about two workgroups
+  // per CU exist (the slabs of a 32-row batch are small) -- not for MFMA occupancy.
+  s.mt = m <= 32 ? 1 : m <= 64 ? 2 : 4;
+  const int mtiles = (m + 32 * s.mt - 1) / (32 * s.mt);
+  int want;
+  if (s.mt < 4) {
+    s.nw = 4;
+    const int wgs = ((n + 127) / 128) * mtiles;
+    want = (512 + wgs - 1) / wgs;
+    if (want > 8) want = 8;
+    if (want > k / (4 * TK)) want = k / (4 * TK);
+  } else {
+    s.nw = (n < 3072 || k <= 2048) ? 4 : 8;
+    const int wgs = ((n + 32 * s.nw - 1) / (32 * s.nw)) * mtiles;
+    want = 256 / wgs;
+    if (want > 8) want = 8;
+    if (want > k / (8 * TK)) want = k / (8 * TK);
+  }
   if (want < 1) want = 1;
   if (const char* e = getenv("VLA_Q4_TUNE")) {
     int a = 0, b = 0;
-    if (sscanf(e, "%d,%d", &a, &b) == 2 && (a == 4 || a == 8) && b >= 1 && b <= 16) {
+    if (sscanf(e, "%d,%d", &a, &b) == 2 && (a == 4 || (a == 8 && s.mt == 4)) && b >= 1 && b <= 16) {
       s.nw = a;
       want = b;
     }
@@ -503,7 +520,7 @@ static int q4_gemm_run(const void* x, const int32_t* qweight, const int32_t* qze
   if (splits > 1 && (!workspace || workspace_bytes < (int64_t)splits * m * n * 4 ||
                      ((uintptr_t)workspace % 16) || ((int64_t)m * n) % 4))
     splits = 1;
-  const int tn = m32 ? 32 * shape.nw : TN, tm = m32 ? TM2 : TM;
+  const int tn = m32 ? 32 * shape.nw : TN, tm = m32 ? 32 * shape.mt : TM;
   dim3 grid((n + tn - 1) / tn, (m + tm - 1) / tm, splits);
   const int kps = k / splits;
   void* dst = splits > 1 ? workspace : out;
@@ -514,10 +531,14 @@ static int q4_gemm_run(const void* x, const int32_t* qweight, const int32_t* qze
   do {                                                                                         \
     if (!m32)                                                                                  \
       hipLaunchKernelGGL((q4_gemm_fast_kernel<Z, SP>), grid, dim3(kThreadsG), 0, s, VLA_Q4_ARGS); \
+    else if (shape.mt == 1)                                                                    \
+      hipLaunchKernelGGL((q4_gemm_m32_kernel<Z, SP, 4, 1>), grid, dim3(256), 0, s, VLA_Q4_ARGS); \
+    else if (shape.mt == 2)                                                                    \
+      hipLaunchKernelGGL((q4_gemm_m32_kernel<Z, SP, 4, 2>), grid, dim3(256), 0, s, VLA_Q4_ARGS); \
     else if (shape.nw == 8)                                                                    \
-      hipLaunchKernelGGL((q4_gemm_m32_kernel<Z, SP, 8>), grid, dim3(512), 0, s, VLA_Q4_ARGS);  \
+      hipLaunchKernelGGL((q4_gemm_m32_kernel<Z, SP, 8, 4>), grid, dim3(512), 0, s, VLA_Q4_ARGS); \
     else                                                                                       \
-      hipLaunchKernelGGL((q4_gemm_m32_kernel<Z, SP, 4>), grid, dim3(256), 0, s, VLA_Q4_ARGS);  \
+      hipLaunchKernelGGL((q4_gemm_m32_kernel<Z, SP, 4, 4>), grid, dim3(256), 0, s, VLA_Q4_ARGS); \
   } while (0)
   if (zero_offset == 0) {
     if (splits > 1) VLA_Q4_LAUNCH(0, true); else VLA_Q4_LAUNCH(0, false);
