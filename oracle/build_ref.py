@@ -1,8 +1,9 @@
 """TEST INFRASTRUCTURE ONLY -- build the reference's own CPU kernels into oracle/_ref/.
 
-Compiles, in place under /root/reference, the two translation units that hold
-the reference's CPU paged-attention and cache kernels
-(csrc/cpu/attention.cpp, csrc/cpu/cache.cpp) behind our binding shim
+Compiles, in place under /root/reference, the translation units that hold
+the reference's CPU paged-attention, cache and glue kernels
+(csrc/cpu/attention.cpp, cache.cpp, layernorm.cpp, pos_encoding.cpp,
+activation.cpp) behind our binding shim
 (oracle/ref_shim.cpp), plus a tiny C library over the reference's host-side
 FNUZ fp8 codec (oracle/ref_fp8_shim.cpp).  Outputs go only to oracle/_ref/
 (git-ignored, but shipped to the GPU box with the tree).
@@ -68,6 +69,10 @@ def build(verbose: bool = False) -> bool:
         os.path.join(HERE, "ref_shim.cpp"),
         os.path.join(REF, "csrc", "cpu", "attention.cpp"),
         os.path.join(REF, "csrc", "cpu", "cache.cpp"),
+        # CPU twins of the glue kernels (RMSNorm, rotary embedding, SiLU-and-mul)
+        os.path.join(REF, "csrc", "cpu", "layernorm.cpp"),
+        os.path.join(REF, "csrc", "cpu", "pos_encoding.cpp"),
+        os.path.join(REF, "csrc", "cpu", "activation.cpp"),
     ]
     if os.path.exists(so) and all(
             os.path.getmtime(so) >= os.path.getmtime(s) for s in srcs):

@@ -1,6 +1,7 @@
 // TEST INFRASTRUCTURE ONLY -- binding shim for the *reference's own* CPU kernels.
 //
-// The reference's csrc/cpu/attention.cpp and csrc/cpu/cache.cpp define the
+// The reference's csrc/cpu/attention.cpp and csrc/cpu/cache.cpp (and, for the glue kernels,
+// layernorm.cpp, pos_encoding.cpp, activation.cpp) define the
 // tensor-signature entry points (csrc/cpu/attention.cpp:421-438, :738-756;
 // csrc/cpu/cache.cpp:85-129), while its csrc/cpu/pybind.cpp includes headers
 // whose signatures were changed to pointer strings (csrc/ops.h:14-30,
@@ -42,7 +43,20 @@ void copy_blocks(std::vector<torch::Tensor>& key_caches,
                  std::vector<torch::Tensor>& value_caches,
                  const torch::Tensor& block_mapping);
 
+// csrc/cpu/layernorm.cpp:90-118, csrc/cpu/pos_encoding.cpp:169-199, csrc/cpu/activation.cpp:80-90:
+// the CPU twins of the glue kernels around attention (signatures as in csrc/ops.h:32-48).
+void rms_norm(torch::Tensor& out, torch::Tensor& input, torch::Tensor& weight, float epsilon);
+void fused_add_rms_norm(torch::Tensor& input, torch::Tensor& residual, torch::Tensor& weight,
+                        float epsilon);
+void rotary_embedding(torch::Tensor& positions, torch::Tensor& query, torch::Tensor& key,
+                      int head_size, torch::Tensor& cos_sin_cache, bool is_neox);
+void silu_and_mul(torch::Tensor& out, torch::Tensor& input);
+
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
+  m.def("rms_norm", &rms_norm);
+  m.def("fused_add_rms_norm", &fused_add_rms_norm);
+  m.def("rotary_embedding", &rotary_embedding);
+  m.def("silu_and_mul", &silu_and_mul);
   m.def("paged_attention_v1", &paged_attention_v1);
   m.def("paged_attention_v2", &paged_attention_v2);
   m.def("reshape_and_cache", &reshape_and_cache);

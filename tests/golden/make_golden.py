@@ -86,6 +86,45 @@ def cache_case(ref, name, dtype, seed):
     print(name, "done")
 
 
+def glue_case(ref, name, dtype, seed):
+    """RMSNorm, fused add+RMSNorm, rotary embedding (NeoX and GPT-J, partial rotation) and
+    SiLU-and-mul through the reference's CPU twins (csrc/cpu/layernorm.cpp, pos_encoding.cpp,
+    activation.cpp); shapes after tests/kernels/test_layernorm.py, test_pos_encoding.py and
+    test_activation.py, small."""
+    g = torch.Generator().manual_seed(seed)
+    t, hidden, eps = 7, 768, 1e-6
+    x = (torch.randn(t, hidden, generator=g) * 0.5).to(dtype)
+    res = (torch.randn(t, hidden, generator=g) * 0.5).to(dtype)
+    w = (1.0 + 0.1 * torch.randn(hidden, generator=g)).to(dtype)
+    out = torch.empty_like(x)
+    ref.rms_norm(out, x, w, eps)
+    fx, fr = x.clone(), res.clone()
+    ref.fused_add_rms_norm(fx, fr, w, eps)
+    # rotary: head size 64, rotating 64 (NeoX) and 32 (GPT-J) dims
+    hq, hkv, d, maxpos = 4, 2, 64, 128
+    pos = torch.randint(0, maxpos, (t, ), generator=g, dtype=torch.int64)
+    rec = {}
+    for tag, rot, neox in (("neox", 64, True), ("gptj", 32, False)):
+        inv = 1.0 / (10000.0**(torch.arange(0, rot, 2, dtype=torch.float32) / rot))
+        fr_ = torch.outer(torch.arange(maxpos, dtype=torch.float32), inv)
+        cache = torch.cat([fr_.cos(), fr_.sin()], dim=-1).to(dtype)
+        q = torch.randn(t, hq * d, generator=g).to(dtype)
+        k = torch.randn(t, hkv * d, generator=g).to(dtype)
+        q2, k2 = q.clone(), k.clone()
+        ref.rotary_embedding(pos, q2, k2, d, cache, neox)
+        rec.update({f"rot_{tag}_cache": bits(cache), f"rot_{tag}_q": bits(q), f"rot_{tag}_k": bits(k),
+                    f"rot_{tag}_q_out": bits(q2), f"rot_{tag}_k_out": bits(k2)})
+    a = torch.randn(t, 2 * 512, generator=g).to(dtype)
+    act = torch.empty(t, 512, dtype=dtype)
+    ref.silu_and_mul(act, a)
+    np.savez_compressed(
+        os.path.join(OUT, name + ".npz"), dtype=str(dtype).replace("torch.", ""), eps=eps,
+        x=bits(x), residual=bits(res), weight=bits(w), rms_out=bits(out), fused_out=bits(fx),
+        fused_residual=bits(fr), positions=pos.numpy(), head_size=d, act_in=bits(a),
+        act_out=bits(act), **rec)
+    print(name, "done")
+
+
 def fnuz_case():
     lib = C.CDLL(build_ref.fp8_so_path())
     lib.ref_fnuz_decode_f32_n.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
@@ -122,6 +161,8 @@ def main():
     attention_case(ref, "attn_f32_d80", torch.float32, [16, 95], 6, 3, 80, 8, False, 3)
     cache_case(ref, "cache_f32", torch.float32, 4)
     cache_case(ref, "cache_bf16", torch.bfloat16, 5)
+    glue_case(ref, "glue_f32", torch.float32, 6)
+    glue_case(ref, "glue_bf16", torch.bfloat16, 7)
     fnuz_case()
 
 

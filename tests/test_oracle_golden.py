@@ -142,3 +142,31 @@ def test_fp8_attention_consistent_with_dequantised_cache():
     vd = O.convert_fp8(vc8, dt, False)
     out16 = O.paged_attention_v1(q, kd, vd, bt, seq_lens, scale, dt)
     assert np.array_equal(out8, out16)
+
+
+@pytest.mark.parametrize("name", ["glue_f32", "glue_bf16"])
+def test_glue_matches_reference_cpu_twins(golden_dir, name):
+    """RMSNorm, fused add+RMSNorm, rotary embedding and SiLU-and-mul against the outputs of the
+    reference's CPU twins.  The oracle restates the CUDA kernels, which round at slightly
+    different points than the CPU twins (RMSNorm: `(scalar_t)(x * rstd) * w` in
+    csrc/layernorm_kernels.cu:43-45 against an all-fp32 product in csrc/cpu/layernorm.cpp:30-36):
+    fp32 agrees to a few ulp, bf16 to two bf16 ulp of the value."""
+    z, dt = _load(golden_dir, name)
+    f = (lambda a: O.from_bits(a, dt)) if dt != O.DT_F32 else (lambda a: np.asarray(a, np.float32))
+    rtol = 4e-6 if dt == O.DT_F32 else 2**-6    # bf16: two roundings against one
+    atol = 1e-6 if dt == O.DT_F32 else 2e-3
+    eps = float(z["eps"])
+    np.testing.assert_allclose(f(O.rms_norm(z["x"], z["weight"], eps, dt)), f(z["rms_out"]), rtol=rtol, atol=atol)
+    fx, fr = O.fused_add_rms_norm(z["x"], z["residual"], z["weight"], eps, dt)
+    np.testing.assert_allclose(f(fr), f(z["fused_residual"]), rtol=rtol, atol=atol)
+    np.testing.assert_allclose(f(fx), f(z["fused_out"]), rtol=rtol, atol=2 * atol)
+    # the CUDA rotary kernel multiplies and subtracts in the model dtype
+    # (csrc/pos_encoding_kernels.cu:10-40), the CPU twin in fp32: where x cos - y sin cancels, a
+    # bf16 result carries the rounding of its O(1) products
+    rot_atol = atol if dt == O.DT_F32 else 3e-2
+    for tag, neox in (("neox", True), ("gptj", False)):
+        q, k = O.rotary_embedding(z["positions"], z[f"rot_{tag}_q"], z[f"rot_{tag}_k"], int(z["head_size"]),
+                                  z[f"rot_{tag}_cache"], neox, dt)
+        np.testing.assert_allclose(f(q), f(z[f"rot_{tag}_q_out"]), rtol=rtol, atol=rot_atol)
+        np.testing.assert_allclose(f(k), f(z[f"rot_{tag}_k_out"]), rtol=rtol, atol=rot_atol)
+    np.testing.assert_allclose(f(O.silu_and_mul(z["act_in"], dt)), f(z["act_out"]), rtol=rtol, atol=atol)
