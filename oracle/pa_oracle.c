@@ -11,7 +11,12 @@
  * are randomized-vs-PyTorch, tests/kernels/test_attention.py:114-274), so this
  * restatement is pinned against outputs of the reference's own CPU kernels
  * compiled from the reference tree (oracle/build_ref.py -> oracle/_ref/) and the
- * fixtures generated from them under tests/golden/.
+ * fixtures generated from them under tests/golden/: paged attention (f32, bf16),
+ * reshape_and_cache, copy_blocks, RMSNorm / rotary / SiLU-and-mul, the FNUZ codec.
+ * Parity unpinned (no reference fixture, no reference CPU implementation): fp16 and
+ * fp8-KV attention, the block-sparse mask, swap_blocks, the AWQ/GPTQ functions, and
+ * prompt attention with or without a cached prefix (checked against a float64
+ * evaluation of the definition the reference's tests use instead).
  *
  * dtype codes: 0 = float16, 1 = bfloat16, 2 = float32.
  * kv codes:    0 = "auto" (cache holds the model dtype), 1 = fp8 e4m3 (OCP e4m3fn,
