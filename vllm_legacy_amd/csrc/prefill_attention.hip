@@ -129,7 +129,8 @@ __device__ __forceinline__ u32x4 pf_keep_first(u32x4 w, int live) {
 // budget, so it runs one workgroup per CU); the LDS images are laid out for DP = 64 or 128
 // dims per row, the query fragments and the K image zero-padded up to a multiple of 32 dims.
 // PREFIX: keys [0, ctx) of a sequence come from the paged cache (FP8: as e4m3 bytes).
-template <class S, int D, bool PREFIX, bool FP8>
+// WIN: a sliding window is in force (p.sliding_window > 0).
+template <class S, int D, bool PREFIX, bool FP8, bool WIN>
 __global__ __launch_bounds__(PF_THREADS, D == 112 ? 1 : 2) void prefill_attention_kernel(PrefillParams p) {
   using T = typename S::T;
   constexpr int DP = D <= 64 ? 64 : 128;
@@ -157,7 +158,9 @@ __global__ __launch_bounds__(PF_THREADS, D == 112 ? 1 : 2) void prefill_attentio
   const int n_new = PREFIX ? p.seq_lens[seq] - ctx : p.cu_seqlens[seq + 1] - seq_start;
   const int q0 = blockIdx.x * PF_BM;
   if (q0 >= n_new) return;
-  const int W = p.sliding_window;
+  // a window known to be absent at compile time keeps its tests out of the tile loop (5 % of
+  // the kernel's time when left to run time)
+  const int W = WIN ? p.sliding_window : 0;
   unsigned char* p_lds = p_all + wave * (32 * P_PITCH);
 
   const T* qb = reinterpret_cast<const T*>(p.q) + (int64_t)seq_start * p.q_stride + (int64_t)head * D;
@@ -449,11 +452,11 @@ namespace {
 
 bool pf_head_size_ok(int d) { return d == 64 || d == 80 || d == 96 || d == 112 || d == 128; }
 
-template <bool PREFIX, bool FP8>
+template <bool PREFIX, bool FP8, bool WIN>
 void pf_launch(const PrefillParams& p, int head_size, int dtype, dim3 grid, hipStream_t s) {
 #define VLA_PF(ST, DD)                                                                       \
-  hipLaunchKernelGGL((prefill_attention_kernel<ST, DD, PREFIX, FP8>), grid, dim3(PF_THREADS), \
-                     0, s, p)
+  hipLaunchKernelGGL((prefill_attention_kernel<ST, DD, PREFIX, FP8, WIN>), grid,           \
+                     dim3(PF_THREADS), 0, s, p)
 #define VLA_PF_D(ST)                     \
   switch (head_size) {                   \
     case 64: VLA_PF(ST, 64); break;      \
@@ -492,7 +495,7 @@ extern "C" int vla_prefill_attention(void* out, const void* query, const void* k
   p.q_stride = query_stride; p.k_stride = key_stride; p.v_stride = value_stride;
   p.out_stride = out_stride; p.scale = scale; p.sliding_window = 0;
   dim3 grid((max_seqlen + PF_BM - 1) / PF_BM, num_heads, num_seqs);
-  pf_launch<false, false>(p, head_size, dtype, grid, (hipStream_t)stream);
+  pf_launch<false, false, false>(p, head_size, dtype, grid, (hipStream_t)stream);
   VLA_HIP_CHECK(hipGetLastError());
   return VLA_OK;
 }
@@ -535,8 +538,14 @@ extern "C" int vla_prefix_prefill_attention(
   p.log2_block_size = block_size == 8 ? 3 : block_size == 16 ? 4 : block_size == 32 ? 5 : 6;
   p.kv_block_stride = kv_block_stride; p.kv_head_stride = kv_head_stride; p.kv_scale = kv_scale;
   dim3 grid((max_query_len + PF_BM - 1) / PF_BM, num_heads, num_seqs);
-  if (fp8) pf_launch<true, true>(p, head_size, dtype, grid, (hipStream_t)stream);
-  else pf_launch<true, false>(p, head_size, dtype, grid, (hipStream_t)stream);
+  hipStream_t s = (hipStream_t)stream;
+  if (p.sliding_window > 0) {
+    if (fp8) pf_launch<true, true, true>(p, head_size, dtype, grid, s);
+    else pf_launch<true, false, true>(p, head_size, dtype, grid, s);
+  } else {
+    if (fp8) pf_launch<true, true, false>(p, head_size, dtype, grid, s);
+    else pf_launch<true, false, false>(p, head_size, dtype, grid, s);
+  }
   VLA_HIP_CHECK(hipGetLastError());
   return VLA_OK;
 }
