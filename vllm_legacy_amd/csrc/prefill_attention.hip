@@ -44,6 +44,19 @@ __device__ __forceinline__ f32x4 pf_mfma<BF16>(u32x4 a, u32x4 b, f32x4 c) {
 }
 
 template <class S>
+__device__ __forceinline__ f32x16 pf_mfma32(u32x4 a, u32x4 b, f32x16 c);
+template <>
+__device__ __forceinline__ f32x16 pf_mfma32<F16>(u32x4 a, u32x4 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a),
+                                                __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+template <>
+__device__ __forceinline__ f32x16 pf_mfma32<BF16>(u32x4 a, u32x4 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a),
+                                                 __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+template <class S>
 __device__ __forceinline__ uint32_t pf_pack2(float a, float b) {
   typename S::T x = S::from_f32(a), y = S::from_f32(b);
   return (uint32_t)__builtin_bit_cast(uint16_t, x) |
@@ -136,20 +149,18 @@ __global__ __launch_bounds__(PF_THREADS, D == 112 ? 1 : 2) void prefill_attentio
   constexpr int DP = D <= 64 ? 64 : 128;
   constexpr int RB = DP * 2;                // bytes per K/V row in LDS
   constexpr int CH = D / 8;                 // live 16-byte chunks per row
-  constexpr int KS = (D + 31) / 32;         // MFMA k-steps of the S^T product
-  constexpr int ND = D / 16;                // output dim tiles
+  constexpr int KS = D / 16;                // 16-deep MFMA slices of the S^T product
+  constexpr int ND = (D + 31) / 32;         // 32-dim output tiles (the last one may be half used)
   constexpr int LD = (PF_BN * CH + PF_THREADS - 1) / PF_THREADS;  // 16-byte loads per thread, tile
   constexpr bool LD_EXACT = (PF_BN * CH) % PF_THREADS == 0;
-  constexpr int P_PITCH = PF_BN * 2 + 16;   // bytes per query row of the probability tile
   static_assert(D % 16 == 0 && D <= 128 && D >= 16, "head size");
   static_assert(PF_BN * RB >= D * PF_BN * 2, "transposed V image fits");
   __shared__ __attribute__((aligned(16))) unsigned char k_lds[PF_BN * RB];
   __shared__ __attribute__((aligned(16))) unsigned char v_lds[PF_BN * RB];
-  __shared__ __attribute__((aligned(16))) unsigned char p_all[4 * 32 * P_PITCH];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int g = lane >> 4, c = lane & 15;
+  const int h = lane >> 5, c = lane & 31;
   const int head = blockIdx.y, seq = blockIdx.z;
   const int kv_head = head / (p.num_heads / p.num_kv_heads);
   const int seq_start = p.cu_seqlens[seq];
@@ -161,33 +172,20 @@ __global__ __launch_bounds__(PF_THREADS, D == 112 ? 1 : 2) void prefill_attentio
   // a window known to be absent at compile time keeps its tests out of the tile loop (5 % of
   // the kernel's time when left to run time)
   const int W = WIN ? p.sliding_window : 0;
-  unsigned char* p_lds = p_all + wave * (32 * P_PITCH);
 
   const T* qb = reinterpret_cast<const T*>(p.q) + (int64_t)seq_start * p.q_stride + (int64_t)head * D;
   const T* kb = reinterpret_cast<const T*>(p.k) + (int64_t)seq_start * p.k_stride + (int64_t)kv_head * D;
   const T* vb = reinterpret_cast<const T*>(p.v) + (int64_t)seq_start * p.v_stride + (int64_t)kv_head * D;
 
-  // ---- query fragments; rows past the sequence are clamped (their results are never stored)
-  u32x4 qf[2][KS];
-  int qpos[2];
-#pragma unroll
-  for (int sub = 0; sub < 2; ++sub) {
-    const int qrow = q0 + 32 * wave + 16 * sub + c;
-    qpos[sub] = ctx + qrow;
+  // ---- query fragments: lane (h, c) holds dims 16 s + 8 h .. + 7 of query c; rows past the
+  // sequence are clamped (their results are never stored)
+  u32x4 qf[KS];
+  const int qrow = q0 + 32 * wave + c;
+  const int qpos = ctx + qrow;
+  {
     const T* qp = qb + (int64_t)min(qrow, n_new - 1) * p.q_stride;
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      if (D % 32 == 0 || g + 4 * ks < CH)
-        qf[sub][ks] = *reinterpret_cast<const u32x4*>(qp + 8 * g + 32 * ks);
-      else
-        qf[sub][ks] = u32x4{0u, 0u, 0u, 0u};
-    }
-  }
-  if (D % 32 != 0) {
-    // the K image's padding chunks are never written again: clear them (everything) once
-    for (int i = tid; i < PF_BN * RB / 16; i += PF_THREADS)
-      reinterpret_cast<u32x4*>(k_lds)[i] = u32x4{0u, 0u, 0u, 0u};
-    __syncthreads();
+    for (int ks = 0; ks < KS; ++ks) qf[ks] = *reinterpret_cast<const u32x4*>(qp + 16 * ks + 8 * h);
   }
   constexpr float kLog2e = 1.4426950408889634f;
   const float scale2 = p.scale * kLog2e;
@@ -195,12 +193,13 @@ __global__ __launch_bounds__(PF_THREADS, D == 112 ? 1 : 2) void prefill_attentio
   // positions of this wave's first and last query
   const int wq_min = ctx + q0 + 32 * wave, wq_max = wq_min + 31;
 
-  f32x4 o[2][ND];
+  // O^T accumulators: lane (h, c) holds dims 32 n + (i & 3) + 8 (i >> 2) + 4 h of query c
+  f32x16 o[ND];
 #pragma unroll
-  for (int sub = 0; sub < 2; ++sub)
+  for (int n = 0; n < ND; ++n)
 #pragma unroll
-    for (int n = 0; n < ND; ++n) o[sub][n] = f32x4{0.f, 0.f, 0.f, 0.f};
-  float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.f, 0.f};
+    for (int i = 0; i < 16; ++i) o[n][i] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
 
   u32x4 kreg[LD], vreg[LD];
 
@@ -315,98 +314,104 @@ __global__ __launch_bounds__(PF_THREADS, D == 112 ? 1 : 2) void prefill_attentio
     if (kpos0 > wq_max) continue;
     if (W > 0 && wq_min - (kpos0 + PF_BN - 1) >= W) continue;
 
-    // ---- online softmax of query c (per query tile) over this lane's keys, in base 2: logits
-    // are scaled by scale * log2(e) so that every exponential is a bare v_exp_f32.  A tile that
-    // lies entirely below the diagonal of this wave's queries, inside the sequence and inside
-    // every window needs no mask (wave-uniform test).
+    // ---- S^T = K q^T for the tile's two 32-key blocks: lane (h, c) gets, of query c, keys
+    // 32 b + (i & 3) + 8 (i >> 2) + 4 h
+    f32x16 st[2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) st[b][i] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        const int row = 32 * b + c;
+        const u32x4 kf = *reinterpret_cast<const u32x4*>(k_lds + row * RB +
+                                                         16 * k_swz<DP>(row, 2 * ks + h));
+        st[b] = pf_mfma32<S>(kf, qf[ks], st[b]);
+      }
+
+    // ---- online softmax of query c over this lane's 32 keys and its partner lane's, in base 2:
+    // logits are scaled by scale * log2(e) so that every exponential is a bare v_exp_f32.  A
+    // tile that lies entirely below the diagonal of this wave's queries, inside the sequence and
+    // inside every window needs no mask (wave-uniform test).
     const bool interior = (kpos0 + PF_BN - 1 <= wq_min) && (kpos0 + PF_BN <= limit) &&
                           (W <= 0 || wq_max - kpos0 < W);
+    float mx = -INFINITY;
 #pragma unroll
-    for (int sub = 0; sub < 2; ++sub) {
-      // S^T = K q^T for this query tile: 4 key blocks of 16 (the two query tiles go one after the
-      // other so that only one logit tile is live)
-      f32x4 st[4];
+    for (int b = 0; b < 2; ++b)
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        const int row = 16 * t + c;
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-          const u32x4 kf = *reinterpret_cast<const u32x4*>(k_lds + row * RB +
-                                                           16 * k_swz<DP>(row, g + 4 * ks));
-          acc = pf_mfma<S>(kf, qf[sub][ks], acc);
+      for (int i = 0; i < 16; ++i) {
+        const int key = kpos0 + 32 * b + (i & 3) + 8 * (i >> 2) + 4 * h;
+        float x = st[b][i] * scale2;
+        if (slope2 != 0.f) x += slope2 * (float)(key - qpos);
+        if (!interior) {
+          bool live = key <= qpos && key < limit;
+          if (W > 0) live = live && (qpos - key < W);
+          x = live ? x : -INFINITY;
         }
-        st[t] = acc;
+        st[b][i] = x;
+        mx = fmaxf(mx, x);
       }
-      float mx = -INFINITY;
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);
+    // a query with no live key so far keeps m = -inf: use 0 as the reference point then
+    const float m_ref = m_new == -INFINITY ? 0.f : m_new;
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_ref);
+    float psum = 0.f;
+    // probabilities rounded to the model dtype, packed in key order: pw[b][j] = keys
+    // 32 b + 8 j + 4 h + 0 .. 3 of query c (two words)
+    u32x2 pw[2][4];
 #pragma unroll
-      for (int t = 0; t < 4; ++t)
+    for (int b = 0; b < 2; ++b)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int key = kpos0 + 16 * t + 4 * g + i;
-          float x = st[t][i] * scale2;
-          if (slope2 != 0.f) x += slope2 * (float)(key - qpos[sub]);
-          if (!interior) {
-            bool live = key <= qpos[sub] && key < limit;
-            if (W > 0) live = live && (qpos[sub] - key < W);
-            x = live ? x : -INFINITY;
-          }
-          st[t][i] = x;
-          mx = fmaxf(mx, x);
-        }
-      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      const float m_new = fmaxf(m_run[sub], mx);
-      // a query with no live key so far keeps m = -inf: use 0 as the reference point then
-      const float m_ref = m_new == -INFINITY ? 0.f : m_new;
-      const float alpha = __builtin_amdgcn_exp2f(m_run[sub] - m_ref);
-      float psum = 0.f;
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
+      for (int j = 0; j < 4; ++j) {
         float e[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          e[i] = __builtin_amdgcn_exp2f(st[t][i] - m_ref);
+          e[i] = __builtin_amdgcn_exp2f(st[b][4 * j + i] - m_ref);
           psum += e[i];
         }
-        u32x2 w;
-        w[0] = pf_pack2<S>(e[0], e[1]);
-        w[1] = pf_pack2<S>(e[2], e[3]);
-        *reinterpret_cast<u32x2*>(p_lds + (16 * sub + c) * P_PITCH + (16 * t + 4 * g) * 2) = w;
+        pw[b][j][0] = pf_pack2<S>(e[0], e[1]);
+        pw[b][j][1] = pf_pack2<S>(e[2], e[3]);
       }
-      l_run[sub] = l_run[sub] * alpha + psum;
-      if (__any(m_new > m_run[sub])) {
-        float a[4];
+    l_run = l_run * alpha + psum;          // this lane's keys only; the halves are added at the end
+    if (__any(m_new > m_run)) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) a[i] = __shfl(alpha, 4 * g + i, 64);
+      for (int n = 0; n < ND; ++n)
 #pragma unroll
-        for (int n = 0; n < ND; ++n)
-#pragma unroll
-          for (int i = 0; i < 4; ++i) o[sub][n][i] *= a[i];
-      }
-      m_run[sub] = m_new;
+        for (int i = 0; i < 16; ++i) o[n][i] *= alpha;
     }
+    m_run = m_new;
 
-    // ---- O += P V
-    __builtin_amdgcn_wave_barrier();
+    // ---- O^T += V^T P^T, 16 keys at a time.  The B operand wants, in lane (h, c), keys
+    // 16 s + 8 h .. + 7 of query c: the lane's own four keys of that group of eight and its
+    // partner's four, which one v_permlane32_swap of the two groups of a slice delivers.
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      u32x4 pf[2];
+    for (int sl = 0; sl < 4; ++sl) {
+      const int b = sl >> 1, j0 = 2 * (sl & 1);
+      u32x4 pf;
 #pragma unroll
-      for (int sub = 0; sub < 2; ++sub)
-        pf[sub] = *reinterpret_cast<const u32x4*>(p_lds + (16 * sub + c) * P_PITCH +
-                                                  (8 * g + 32 * kk) * 2);
-      const int r0 = 32 * kk + 8 * g + (c >> 2);   // key row this lane addresses (first 4 keys)
+      for (int w = 0; w < 2; ++w) {
+        const auto r = __builtin_amdgcn_permlane32_swap(pw[b][j0][w], pw[b][j0 + 1][w], false, false);
+        pf[w] = r[0];        // keys 8 h' + 0 .. 3 of the slice (two per word)
+        pf[2 + w] = r[1];    // keys 8 h' + 4 .. 7
+      }
 #pragma unroll
       for (int n = 0; n < ND; ++n) {
         u32x4 vf;
         if (pre) {
-          // row = dim 16n + c, 128-byte rows of 64 keys: keys 8g + 32kk .. +7 are one chunk
-          const int row = 16 * n + c;
+          // cached tile: row = dim 32 n + c, 128-byte rows of 64 keys, keys 16 sl + 8 h .. + 7 are
+          // one chunk
+          const int row = 32 * n + c;
           vf = *reinterpret_cast<const u32x4*>(v_lds + row * (PF_BN * 2) +
-                                               16 * k_swz<64>(row, g + 4 * kk));
+                                               16 * k_swz<64>(row, 2 * sl + h));
         } else {
-          const int ch = 2 * n + ((c & 3) >> 1), half = (c & 1) * 8;
+          // row-major tile: each group of 16 lanes reads 4 keys x 16 dims and receives them
+          // transposed, one dim per lane
+          const int i16 = c & 15;
+          const int r0 = 16 * sl + 8 * h + (i16 >> 2);
+          const int ch = 4 * n + 2 * (c >> 4) + ((i16 & 3) >> 1), half = (i16 & 1) * 8;
           typedef short s16x4 __attribute__((ext_vector_type(4)));
           typedef s16x4 __attribute__((address_space(3))) * lds_ptr;
           const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
@@ -416,30 +421,28 @@ __global__ __launch_bounds__(PF_THREADS, D == 112 ? 1 : 2) void prefill_attentio
           const u32x2 lo2 = __builtin_bit_cast(u32x2, lo), hi2 = __builtin_bit_cast(u32x2, hi);
           vf[0] = lo2[0]; vf[1] = lo2[1]; vf[2] = hi2[0]; vf[3] = hi2[1];
         }
-        o[0][n] = pf_mfma<S>(pf[0], vf, o[0][n]);
-        o[1][n] = pf_mfma<S>(pf[1], vf, o[1][n]);
+        o[n] = pf_mfma32<S>(vf, pf, o[n]);
       }
     }
-    __builtin_amdgcn_wave_barrier();
   }
 
-  // ---- normalise and store: lane (g, c) holds dim 16n + c of queries 4g..4g+3 of each tile
+  // ---- normalise and store: lane (h, c) holds dims 32 n + (i & 3) + 8 (i >> 2) + 4 h of query c
+  l_run += __shfl_xor(l_run, 32, 64);
+  if (qrow < n_new) {
+    T* op = reinterpret_cast<T*>(p.out) + (int64_t)(seq_start + qrow) * p.out_stride + (int64_t)head * D;
+    const float inv = 1.f / l_run;
 #pragma unroll
-  for (int sub = 0; sub < 2; ++sub) {
-    float l = l_run[sub];
-    l += __shfl_xor(l, 16, 64);
-    l += __shfl_xor(l, 32, 64);
+    for (int n = 0; n < ND; ++n)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const float li = __shfl(l, 4 * g + i, 64);
-      const int row = q0 + 32 * wave + 16 * sub + 4 * g + i;
-      if (row >= n_new) continue;
-      T* op = reinterpret_cast<T*>(p.out) + (int64_t)(seq_start + row) * p.out_stride +
-              (int64_t)head * D;
-      const float inv = 1.f / li;
-#pragma unroll
-      for (int n = 0; n < ND; ++n) op[16 * n + c] = S::from_f32(o[sub][n][i] * inv);
-    }
+      for (int j = 0; j < 4; ++j) {
+        const int d0 = 32 * n + 8 * j + 4 * h;
+        if (D % 32 == 0 || d0 < D) {
+          u32x2 w;
+          w[0] = pf_pack2<S>(o[n][4 * j] * inv, o[n][4 * j + 1] * inv);
+          w[1] = pf_pack2<S>(o[n][4 * j + 2] * inv, o[n][4 * j + 3] * inv);
+          *reinterpret_cast<u32x2*>(op + d0) = w;
+        }
+      }
   }
 }
 
