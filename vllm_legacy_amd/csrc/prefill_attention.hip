@@ -167,7 +167,8 @@ __global__ __launch_bounds__(PF_THREADS, D == 112 ? 1 : 2) void prefill_attentio
   const int ctx = PREFIX ? p.ctx_lens[seq] : 0;
   // number of new tokens; positions are absolute: query i sits at ctx + i
   const int n_new = PREFIX ? p.seq_lens[seq] - ctx : p.cu_seqlens[seq + 1] - seq_start;
-  const int q0 = blockIdx.x * PF_BM;
+  // the longest key walks (last query tiles) are dispatched first
+  const int q0 = (gridDim.x - 1 - blockIdx.x) * PF_BM;
   if (q0 >= n_new) return;
   // a window known to be absent at compile time keeps its tests out of the tile loop (5 % of
   // the kernel's time when left to run time)
