@@ -338,27 +338,40 @@ __global__ __launch_bounds__(PF_THREADS, D == 112 ? 1 : 2) void prefill_attentio
     // inside every window needs no mask (wave-uniform test).
     const bool interior = (kpos0 + PF_BN - 1 <= wq_min) && (kpos0 + PF_BN <= limit) &&
                           (W <= 0 || wq_max - kpos0 < W);
+    // Unmasked tiles without ALiBi (most of a long prompt) take the maximum of the raw products
+    // and fold the scale into the exponent's multiply-add; scale > 0 keeps the maximum where it is.
+    const bool plain = interior && slope2 == 0.f && scale2 > 0.f;
     float mx = -INFINITY;
+    if (plain) {
 #pragma unroll
-    for (int b = 0; b < 2; ++b)
+      for (int b = 0; b < 2; ++b)
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int key = kpos0 + 32 * b + (i & 3) + 8 * (i >> 2) + 4 * h;
-        float x = st[b][i] * scale2;
-        if (slope2 != 0.f) x += slope2 * (float)(key - qpos);
-        if (!interior) {
-          bool live = key <= qpos && key < limit;
-          if (W > 0) live = live && (qpos - key < W);
-          x = live ? x : -INFINITY;
+        for (int i = 0; i < 16; ++i) mx = fmaxf(mx, st[b][i]);
+      mx *= scale2;
+    } else {
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int key = kpos0 + 32 * b + (i & 3) + 8 * (i >> 2) + 4 * h;
+          float x = st[b][i] * scale2;
+          if (slope2 != 0.f) x += slope2 * (float)(key - qpos);
+          if (!interior) {
+            bool live = key <= qpos && key < limit;
+            if (W > 0) live = live && (qpos - key < W);
+            x = live ? x : -INFINITY;
+          }
+          st[b][i] = x;
+          mx = fmaxf(mx, x);
         }
-        st[b][i] = x;
-        mx = fmaxf(mx, x);
-      }
+    }
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     const float m_new = fmaxf(m_run, mx);
     // a query with no live key so far keeps m = -inf: use 0 as the reference point then
     const float m_ref = m_new == -INFINITY ? 0.f : m_new;
     const float alpha = __builtin_amdgcn_exp2f(m_run - m_ref);
+    // exponent of element x: x * es - m_ref, with es = scale2 for raw products and 1 otherwise
+    const float es = plain ? scale2 : 1.f;
     float psum = 0.f;
     // probabilities rounded to the model dtype, packed in key order: pw[b][j] = keys
     // 32 b + 8 j + 4 h + 0 .. 3 of query c (two words)
@@ -370,7 +383,7 @@ __global__ __launch_bounds__(PF_THREADS, D == 112 ? 1 : 2) void prefill_attentio
         float e[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          e[i] = __builtin_amdgcn_exp2f(st[b][4 * j + i] - m_ref);
+          e[i] = __builtin_amdgcn_exp2f(__builtin_fmaf(st[b][4 * j + i], es, -m_ref));
           psum += e[i];
         }
         pw[b][j][0] = pf_pack2<S>(e[0], e[1]);
