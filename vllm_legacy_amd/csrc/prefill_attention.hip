@@ -56,11 +56,18 @@ __device__ __forceinline__ f32x16 pf_mfma32<BF16>(u32x4 a, u32x4 b, f32x16 c) {
                                                  __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
+// two fp32 -> one word of two model-dtype values (round to nearest even), as one packed convert
 template <class S>
-__device__ __forceinline__ uint32_t pf_pack2(float a, float b) {
-  typename S::T x = S::from_f32(a), y = S::from_f32(b);
-  return (uint32_t)__builtin_bit_cast(uint16_t, x) |
-         ((uint32_t)__builtin_bit_cast(uint16_t, y) << 16);
+__device__ __forceinline__ uint32_t pf_pack2(float a, float b);
+template <>
+__device__ __forceinline__ uint32_t pf_pack2<F16>(float a, float b) {
+  const f32x2 v = {a, b};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2));
+}
+template <>
+__device__ __forceinline__ uint32_t pf_pack2<BF16>(float a, float b) {
+  const f32x2 v = {a, b};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
 }
 
 struct PrefillParams {
