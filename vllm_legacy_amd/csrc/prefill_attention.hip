@@ -346,16 +346,44 @@ __global__ __launch_bounds__(PF_THREADS, D == 112 ? 1 : 2) void prefill_attentio
     const bool interior = (kpos0 + PF_BN - 1 <= wq_min) && (kpos0 + PF_BN <= limit) &&
                           (W <= 0 || wq_max - kpos0 < W);
     // Unmasked tiles without ALiBi (most of a long prompt) take the maximum of the raw products
-    // and fold the scale into the exponent's multiply-add; scale > 0 keeps the maximum where it is.
+    // and fold the scale into the exponent's multiply-add; scale > 0 keeps the maximum where it
+    // is.  The two cases are separate code all the way to the packed probabilities: merged into
+    // selects, the masking arithmetic would run on every tile.
     const bool plain = interior && slope2 == 0.f && scale2 > 0.f;
-    float mx = -INFINITY;
+    float m_new, alpha, psum = 0.f;
+    // probabilities rounded to the model dtype, packed in key order: pw[b][j] = keys
+    // 32 b + 8 j + 4 h + 0 .. 3 of query c (two words)
+    u32x2 pw[2][4];
+    // exponent of element x: x * es - m_ref
+    auto finish = [&](float mx, const float es) {
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      m_new = fmaxf(m_run, mx);
+      // a query with no live key so far keeps m = -inf: use 0 as the reference point then
+      const float m_ref = m_new == -INFINITY ? 0.f : m_new;
+      alpha = __builtin_amdgcn_exp2f(m_run - m_ref);
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float e[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            e[i] = __builtin_amdgcn_exp2f(__builtin_fmaf(st[b][4 * j + i], es, -m_ref));
+            psum += e[i];
+          }
+          pw[b][j][0] = pf_pack2<S>(e[0], e[1]);
+          pw[b][j][1] = pf_pack2<S>(e[2], e[3]);
+        }
+    };
     if (plain) {
+      float mx = -INFINITY;
 #pragma unroll
       for (int b = 0; b < 2; ++b)
 #pragma unroll
         for (int i = 0; i < 16; ++i) mx = fmaxf(mx, st[b][i]);
-      mx *= scale2;
+      finish(mx * scale2, scale2);
     } else {
+      float mx = -INFINITY;
 #pragma unroll
       for (int b = 0; b < 2; ++b)
 #pragma unroll
@@ -371,31 +399,8 @@ __global__ __launch_bounds__(PF_THREADS, D == 112 ? 1 : 2) void prefill_attentio
           st[b][i] = x;
           mx = fmaxf(mx, x);
         }
+      finish(mx, 1.f);
     }
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m_run, mx);
-    // a query with no live key so far keeps m = -inf: use 0 as the reference point then
-    const float m_ref = m_new == -INFINITY ? 0.f : m_new;
-    const float alpha = __builtin_amdgcn_exp2f(m_run - m_ref);
-    // exponent of element x: x * es - m_ref, with es = scale2 for raw products and 1 otherwise
-    const float es = plain ? scale2 : 1.f;
-    float psum = 0.f;
-    // probabilities rounded to the model dtype, packed in key order: pw[b][j] = keys
-    // 32 b + 8 j + 4 h + 0 .. 3 of query c (two words)
-    u32x2 pw[2][4];
-#pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        float e[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          e[i] = __builtin_amdgcn_exp2f(__builtin_fmaf(st[b][4 * j + i], es, -m_ref));
-          psum += e[i];
-        }
-        pw[b][j][0] = pf_pack2<S>(e[0], e[1]);
-        pw[b][j][1] = pf_pack2<S>(e[2], e[3]);
-      }
     l_run = l_run * alpha + psum;          // this lane's keys only; the halves are added at the end
     if (__any(m_new > m_run)) {
 #pragma unroll
