@@ -30,6 +30,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
 HBM_MEASURED_READ_GBS = 6353.0  # linear read-only stream measured on the part
+MFMA_F16_PEAK_TFLOPS = 2500.0   # dense fp16/bf16 MFMA peak of the part
 
 
 def parse():
@@ -379,6 +380,50 @@ def main():
         attn_ms = sum(a.elapsed_time(b_) for a, b_ in evs) / len(evs)
     achieved = algo_bytes / (attn_ms * 1e-3) / 1e9
 
+    # ---- second kernel family: the int4 dequant-GEMMs of one layer at M = batch, timed the same
+    # way (HIP events on their stream, every layer's own weights so nothing is cache-resident)
+    gemm = None
+    if args.quant != "none":
+        names = ("qkv_proj", "o_proj", "gate_up_proj", "down_proj")
+        with torch.cuda.stream(stream), torch.inference_mode():
+            xs = {}
+            flops = 0
+            for nme in names:
+                lin = getattr(layer0, nme)
+                k_in = lin.qweight.shape[0] * (8 if args.quant == "gptq" else 1)
+                n_out = lin.scales.shape[1]
+                xs[nme] = torch.empty((B, k_in), dtype=model.dtype, device=device).uniform_(-1, 1)
+                flops += 2 * B * k_in * n_out
+            for lyr in model.layers:                      # warm-up: every layer once
+                for nme in names:
+                    getattr(lyr, nme)(xs[nme])
+            torch.cuda.synchronize()
+            evs = []
+            for lyr in model.layers:
+                a, b_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record(stream)
+                for nme in names:
+                    getattr(lyr, nme)(xs[nme])
+                b_.record(stream)
+                evs.append((a, b_))
+            torch.cuda.synchronize()
+            # the median layer: eager launches leave host gaps in the slowest ones
+            ts = sorted(a.elapsed_time(b_) for a, b_ in evs)
+            layer_ms = ts[len(ts) // 2]
+        gemm = {
+            "kernel": "q4_gemm_m32_kernel (+ split-K reduce), qkv + o + gate_up + down of one layer",
+            "bound": "mfma",
+            "achieved": round(flops / (layer_ms * 1e-3) / 1e12, 1),
+            "peak": MFMA_F16_PEAK_TFLOPS,
+            "unit": "TFLOP/s",
+            "frac": round(flops / (layer_ms * 1e-3) / 1e12 / MFMA_F16_PEAK_TFLOPS, 4),
+            "traffic": None,
+            "algorithmic_flops_per_layer": flops,
+            "layer_ms": round(layer_ms, 4),
+            "note": "eager launches, includes launch gaps; tools/gemm_bench.py times the same "
+                    "kernels from a graph",
+        }
+
     # HBM bytes per launch from the committed PMC passes, when they were taken on this workload
     traffic = None
     try:
@@ -434,6 +479,8 @@ def main():
                 "attention_share_of_step": round(attn_ms * len(caches) / ms_per_step, 3),
             },
         }
+        if gemm is not None:
+            result["roofline_gemm"] = gemm
         if world == 1 and not args.no_cpu_baseline:
             try:
                 result["cpu_baseline"] = cpu_baseline(args)
