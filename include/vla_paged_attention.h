@@ -239,6 +239,20 @@ int vla_prefix_prefill_attention(void* out, const void* query, const void* key, 
                                  int sliding_window, int dtype, int kv_cache_dtype, float kv_scale,
                                  void* stream);
 
+/* Several int4 products in one launch, for the experts of the reference's quantized Mixtral block
+ * (vllm/model_executor/models/mixtral_quant.py:129-156, which runs one awq/gptq GEMM per expert
+ * over all tokens): out[r, :] = x[r, :] . W[e] for the rows r in row_offsets[e] .. row_offsets[e+1]
+ * (int32 [num_sets + 1] on the device, so the launch needs no host knowledge of the routing and
+ * can be captured).  qweight / qzeros / scales hold the k-packed tensors of all sets back to back
+ * ([num_sets, k/8, n], [num_sets, k/group, n/8], [num_sets, k/group, n]).  Rows outside every set
+ * are left untouched (zero when the product is split along K).  max_rows_per_set bounds the grid;
+ * group a multiple of 64.  workspace: vla_q4_gemm_grouped_workspace_bytes or NULL. */
+int64_t vla_q4_gemm_grouped_workspace_bytes(int total_rows, int n, int k, int group, int num_sets);
+int vla_q4_gemm_grouped(const void* x, const int32_t* qweight, const int32_t* qzeros,
+                        const void* scales, void* out, const int* row_offsets, int num_sets,
+                        int total_rows, int max_rows_per_set, int n, int k, int group,
+                        int zero_offset, void* workspace, int64_t workspace_bytes, void* stream);
+
 /* ---- all-reduce over xGMI peer memory ---------------------------------------------------------- */
 
 /* Together these take the place of the reference's custom all-reduce (csrc/custom_all_reduce.cuh,

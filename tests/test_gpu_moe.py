@@ -24,12 +24,14 @@ def test_routed_moe_matches_dense_loop_and_oracle(tokens):
     with torch.inference_mode():
         routed = moe.forward_routed(x)
         dense = moe.forward_dense(x)
+        grouped = moe.forward_grouped(x)
         rw, sel = moe.route(x)
     torch.cuda.synchronize()
     # same values: a skipped expert contributes exact zeros in the dense loop; the per-expert
     # batches may get another K-split count from the GEMM than the full batch (fp32 partial sums
     # in another order), so the bar is a couple of fp16 roundings, not bit equality
     torch.testing.assert_close(routed.float(), dense.float(), atol=4e-3, rtol=4e-3)
+    torch.testing.assert_close(grouped.float(), dense.float(), atol=4e-3, rtol=4e-3)
     # every token got exactly top_k experts and normalised weights
     assert sel.shape == (tokens, 2) and torch.allclose(rw.sum(-1), torch.ones(tokens, device="cuda"))
 

@@ -28,12 +28,24 @@ def timed(fn, iters=10):
 def main():
     moe = QuantMixtralMoE(4096, 14336, 8, 2, "awq", 128, "cuda", seed=0)
     res = []
-    for tokens in (256, 1024, 4096):
+    for tokens in (16, 64, 256, 1024, 4096):
         x = torch.randn((tokens, 4096), device="cuda").half()
         with torch.inference_mode():
             r = timed(lambda: moe.forward_routed(x))
             d = timed(lambda: moe.forward_dense(x))
-        res.append({"tokens": tokens, "routed_ms": round(r, 3), "dense_loop_ms": round(d, 3)})
+            g = timed(lambda: moe.forward_grouped(x))
+            # the grouped path has no host synchronisation: time it from a graph as decode runs it
+            stream = torch.cuda.Stream()
+            with torch.cuda.stream(stream):
+                moe.forward_grouped(x)
+                torch.cuda.synchronize()
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph, stream=stream):
+                    for _ in range(4):
+                        moe.forward_grouped(x)
+            gg = timed(graph.replay) / 4
+        res.append({"tokens": tokens, "routed_ms": round(r, 3), "dense_loop_ms": round(d, 3),
+                    "grouped_ms": round(g, 3), "grouped_graph_ms": round(gg, 3)})
     print(json.dumps(res))
 
 

@@ -444,6 +444,33 @@ def q4_gemm_packed(x: torch.Tensor, qweight: torch.Tensor, qzeros: torch.Tensor,
     return out
 
 
+def q4_gemm_grouped(x: torch.Tensor, qweight: torch.Tensor, qzeros: torch.Tensor,
+                    scales: torch.Tensor, row_offsets: torch.Tensor, zero_offset: int,
+                    max_rows_per_set: Optional[int] = None) -> torch.Tensor:
+    """x [rows, k] fp16, rows sorted by weight set; qweight [sets, k/8, n], qzeros
+    [sets, k/group, n/8], scales [sets, k/group, n] (k-packed); row_offsets [sets + 1] int32 on
+    the device.  Returns [rows, n]; rows outside every set come back zero."""
+    _require_cuda(x, qweight, qzeros, scales, row_offsets)
+    assert x.dtype == torch.float16 and scales.dtype == torch.float16
+    assert row_offsets.dtype == torch.int32 and row_offsets.is_contiguous()
+    assert qweight.is_contiguous() and qzeros.is_contiguous() and scales.is_contiguous()
+    x = x.contiguous()
+    rows, k = x.shape
+    sets, _, n = qweight.shape
+    assert row_offsets.numel() == sets + 1
+    group = k // qzeros.shape[1]
+    out = torch.zeros((rows, n), dtype=x.dtype, device=x.device)
+    L = _lib.lib()
+    ws_bytes = L.vla_q4_gemm_grouped_workspace_bytes(rows, n, k, group, sets)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device) if ws_bytes else None
+    with torch.cuda.device(x.device):
+        check(L.vla_q4_gemm_grouped(
+            x.data_ptr(), qweight.data_ptr(), qzeros.data_ptr(), scales.data_ptr(), out.data_ptr(),
+            row_offsets.data_ptr(), sets, rows, rows if max_rows_per_set is None else max_rows_per_set,
+            n, k, group, zero_offset, _ptr(ws), ws_bytes, _stream(x.device)), "q4_gemm_grouped")
+    return out
+
+
 class SplitKSlabs:
     """fp32 partial products [num_slabs, m, n] of an int4 GEMM whose K range was split, waiting
     for a consumer (fused_add_rms_norm_splitk / rotary_reshape_and_cache) to sum them."""

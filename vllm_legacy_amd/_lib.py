@@ -29,7 +29,8 @@ EXPORTS = [
     "vla_fused_add_rms_norm", "vla_rotary_embedding", "vla_silu_and_mul",
     "vla_prefill_attention", "vla_prefix_prefill_attention", "vla_ar_region_bytes", "vla_ar_alloc_region",
     "vla_ar_free_region", "vla_ar_export", "vla_ar_import", "vla_ar_unimport", "vla_ar_create", "vla_ar_destroy",
-    "vla_ar_all_reduce", "vla_ar_error_count", "vla_q4_gemm_packed_partial", "vla_rotary_reshape_and_cache", "vla_fused_add_rms_norm_splitk",
+    "vla_ar_all_reduce", "vla_ar_error_count", "vla_q4_gemm_grouped", "vla_q4_gemm_grouped_workspace_bytes",
+    "vla_q4_gemm_packed_partial", "vla_rotary_reshape_and_cache", "vla_fused_add_rms_norm_splitk",
 ]
 
 
@@ -82,6 +83,9 @@ def lib():
         L.vla_prefix_prefill_attention.argtypes = [p, p, p, p, p, p, p, i, p, p, p, i, i, i, i, i, i,
                                                    i64, i64, i64, i64, i64, i64, f, p, i, i, i, f,
                                                    p]
+        L.vla_q4_gemm_grouped_workspace_bytes.argtypes = [i, i, i, i, i]
+        L.vla_q4_gemm_grouped_workspace_bytes.restype = i64
+        L.vla_q4_gemm_grouped.argtypes = [p, p, p, p, p, p, i, i, i, i, i, i, i, p, i64, p]
         L.vla_ar_region_bytes.argtypes = [i64, p]
         L.vla_ar_alloc_region.argtypes = [i64, p]
         L.vla_ar_free_region.argtypes = [p]

@@ -204,11 +204,22 @@ __global__ __launch_bounds__(kThreadsG, 2) void q4_gemm_fast_kernel(
 // batches, where the work is reading the weights once (HBM-bound) and a 128-row tile would spend
 // MFMA passes and x traffic on rows that do not exist.
 
-template <int ZOFF, bool SPLIT, int NW, int MT>
+// GROUPED (several weight sets in one launch, e.g. the experts of an MoE block): x and out hold
+// the row blocks of all sets back to back, gp.row_offsets[e] .. [e + 1] on the device says which
+// rows belong to set e, blockIdx.y = e * tiles_per_set + row tile, and a workgroup whose tile
+// lies past its set's rows leaves at once.
+struct Q4Groups {
+  const int* row_offsets;      // [num_sets + 1]
+  int tiles_per_set;
+  int total_rows;              // rows of x / out, the slab pitch of a split product
+  int64_t w_stride, z_stride, s_stride;   // elements between consecutive sets
+};
+
+template <int ZOFF, bool SPLIT, int NW, int MT, bool GROUPED = false>
 __global__ __launch_bounds__(64 * NW) void q4_gemm_m32_kernel(
     const _Float16* __restrict__ x, const uint32_t* __restrict__ qw,
     const uint32_t* __restrict__ qz, const _Float16* __restrict__ scales, void* __restrict__ outp,
-    int m, int n, int k, int group_size, int k_per_split) {
+    int m, int n, int k, int group_size, int k_per_split, Q4Groups gp = Q4Groups{}) {
   constexpr int THREADS = 64 * NW;
   constexpr int TMW = 32 * MT;                   // rows per workgroup
   constexpr int X2_TILE_BYTES = TMW * TK * 2;    // one LDS buffer: 16 KiB at MT = 4
@@ -221,7 +232,20 @@ __global__ __launch_bounds__(64 * NW) void q4_gemm_m32_kernel(
   const int lane = tid & 63;
   const int wn = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int h = lane >> 5, c = lane & 31;
-  const int n0 = blockIdx.x * (32 * NW), m0 = blockIdx.y * TMW;
+  int tile_y = blockIdx.y, row_base = 0, slab_rows = m;
+  if constexpr (GROUPED) {
+    const int set = blockIdx.y / gp.tiles_per_set;
+    tile_y = blockIdx.y % gp.tiles_per_set;
+    row_base = gp.row_offsets[set];
+    m = gp.row_offsets[set + 1] - row_base;
+    slab_rows = gp.total_rows;
+    if (tile_y * TMW >= m) return;
+    x += (int64_t)row_base * k;
+    qw += (int64_t)set * gp.w_stride;
+    qz += (int64_t)set * gp.z_stride;
+    scales += (int64_t)set * gp.s_stride;
+  }
+  const int n0 = blockIdx.x * (32 * NW), m0 = tile_y * TMW;
   const int k_begin = blockIdx.z * k_per_split;
   const int k_end = min(k, k_begin + k_per_split);
   const int nsteps = (k_end - k_begin) / TK;
@@ -384,9 +408,9 @@ __global__ __launch_bounds__(64 * NW) void q4_gemm_m32_kernel(
       const int row = m0 + 32 * a + (i & 3) + 8 * (i >> 2) + 4 * h;
       if (row >= m) continue;
       if constexpr (SPLIT)
-        reinterpret_cast<float*>(outp)[((int64_t)blockIdx.z * m + row) * n + ncol] = acc[a][i];
+        reinterpret_cast<float*>(outp)[((int64_t)blockIdx.z * slab_rows + row_base + row) * n + ncol] = acc[a][i];
       else
-        reinterpret_cast<_Float16*>(outp)[(int64_t)row * n + ncol] = (_Float16)acc[a][i];
+        reinterpret_cast<_Float16*>(outp)[(int64_t)(row_base + row) * n + ncol] = (_Float16)acc[a][i];
     }
 }
 
@@ -590,5 +614,75 @@ extern "C" int vla_awq_repack(const int32_t* qweight, const int32_t* qzeros, int
   hipLaunchKernelGGL(awq_repack_zeros_kernel, dim3((unsigned)((zw + 255) / 256)), dim3(256), 0, s,
                      (const uint32_t*)qzeros, (uint32_t*)out_qzeros, zw);
   VLA_HIP_CHECK(hipGetLastError());
+  return VLA_OK;
+}
+
+// Grouped product for small row blocks (MoE experts at decode): 64-row tiles, 128-column
+// workgroups, K split into at most 8 slices until the launch has about two workgroups per CU per
+// expected active tile; the slabs are summed by the reduction kernel.
+extern "C" int64_t vla_q4_gemm_grouped_workspace_bytes(int total_rows, int n, int k, int group,
+                                                       int num_sets) {
+  if (total_rows <= 0 || n <= 0 || k <= 0 || group <= 0 || num_sets <= 0) return 0;
+  const int wgs = ((n + 127) / 128) * num_sets;
+  int want = (512 + wgs - 1) / wgs;
+  if (want > 8) want = 8;
+  if (want > k / (4 * TK)) want = k / (4 * TK);
+  if (want < 1) want = 1;
+  const int unit = group > TK ? group : TK;
+  while (want > 1 && (k % (want * unit)) != 0) --want;
+  return want > 1 ? (int64_t)want * total_rows * n * 4 : 0;
+}
+
+extern "C" int vla_q4_gemm_grouped(const void* x, const int32_t* qweight, const int32_t* qzeros,
+                                   const void* scales, void* out, const int* row_offsets,
+                                   int num_sets, int total_rows, int max_rows_per_set, int n, int k,
+                                   int group, int zero_offset, void* workspace,
+                                   int64_t workspace_bytes, void* stream) {
+  (void)hipGetLastError();
+  if (!x || !qweight || !qzeros || !scales || !out || !row_offsets || num_sets <= 0 ||
+      total_rows < 0 || max_rows_per_set < 0)
+    return VLA_ERR_ARG;
+  if (n % 8 || k % TK || group <= 0 || group % TK || k % group ||
+      (zero_offset != 0 && zero_offset != 1))
+    return VLA_ERR_QUANT_SHAPE;
+  if (((uintptr_t)x % 16) || ((uintptr_t)out % 8)) return VLA_ERR_ARG;
+  if (total_rows == 0 || max_rows_per_set == 0) return VLA_OK;
+  const int64_t need = vla_q4_gemm_grouped_workspace_bytes(total_rows, n, k, group, num_sets);
+  int splits = need ? (int)(need / ((int64_t)total_rows * n * 4)) : 1;
+  if (splits > 1 && (!workspace || workspace_bytes < need || ((uintptr_t)workspace % 16) ||
+                     ((int64_t)total_rows * n) % 4))
+    splits = 1;
+  Q4Groups gp;
+  gp.row_offsets = row_offsets;
+  gp.tiles_per_set = (max_rows_per_set + 63) / 64;
+  gp.total_rows = total_rows;
+  gp.w_stride = (int64_t)(k / 8) * n;
+  gp.z_stride = (int64_t)(k / group) * (n / 8);
+  gp.s_stride = (int64_t)(k / group) * n;
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid((n + 127) / 128, num_sets * gp.tiles_per_set, splits);
+  const int kps = k / splits;
+  void* dst = splits > 1 ? workspace : out;
+  if (splits > 1) {
+    // rows of sets that got fewer rows than a tile are never written: the sum must not see junk
+    VLA_HIP_CHECK(hipMemsetAsync(workspace, 0, (size_t)need, s));
+  }
+#define VLA_Q4G(Z, SP)                                                                          \
+  hipLaunchKernelGGL((q4_gemm_m32_kernel<Z, SP, 4, 2, true>), grid, dim3(256), 0, s,            \
+                     (const _Float16*)x, (const uint32_t*)qweight, (const uint32_t*)qzeros,     \
+                     (const _Float16*)scales, dst, 0, n, k, group, kps, gp)
+  if (zero_offset == 0) {
+    if (splits > 1) VLA_Q4G(0, true); else VLA_Q4G(0, false);
+  } else {
+    if (splits > 1) VLA_Q4G(1, true); else VLA_Q4G(1, false);
+  }
+#undef VLA_Q4G
+  VLA_HIP_CHECK(hipGetLastError());
+  if (splits > 1) {
+    const int64_t elems = (int64_t)total_rows * n;
+    hipLaunchKernelGGL(q4_splitk_reduce_kernel, dim3((unsigned)((elems / 4 + 255) / 256)),
+                       dim3(256), 0, s, (const float*)workspace, (_Float16*)out, elems, splits);
+    VLA_HIP_CHECK(hipGetLastError());
+  }
   return VLA_OK;
 }

@@ -10,6 +10,8 @@ the end.  Two things differ in execution, not in values:
   (gather -> w13 GEMM -> SiLU*mul -> w2 GEMM -> weighted scatter-add), 1/4 of the GEMM work at
   top-2 of 8.  Adding the skipped zero contributions would not change any element, and the
   per-token accumulation order (ascending expert index) is the reference's.
+* With AWQ experts the per-expert loop is one grouped GEMM launch per projection over rows sorted
+  by expert on the device (forward_grouped): no host synchronisation, graph-capturable.
 * w1 and w3 are stored side by side as one [hidden, 2*ffn] int4 matrix so that one GEMM feeds the
   fused SiLU*mul kernel (the reference's TODO at :82).
 """
@@ -22,6 +24,7 @@ import torch.nn as nn
 from vllm_legacy_amd.distributed.communication_op import tensor_model_parallel_all_reduce
 from vllm_legacy_amd.distributed.parallel_state import (get_tensor_model_parallel_rank,
                                                         get_tensor_model_parallel_world_size)
+from vllm_legacy_amd import _custom_ops as ops
 from vllm_legacy_amd.layers import SiluAndMul
 from vllm_legacy_amd.model.llama_decode import QuantLinear
 
@@ -74,14 +77,69 @@ class QuantMixtralMoE(nn.Module):
         routing_weights /= routing_weights.sum(dim=-1, keepdim=True)
         return routing_weights, selected_experts
 
-    # below this many tokens every expert's weights are the cost and a 128-row GEMM tile is not
-    # full either way: the dense loop (no host synchronisation, graph-capturable) is used
+    # GPTQ experts (no grouped launch yet): below this many tokens the per-expert gather of
+    # forward_routed (host-synchronising) costs more than it saves and the dense loop is used
     ROUTED_MIN_TOKENS = 512
 
     def forward(self, hidden_states: torch.Tensor) -> torch.Tensor:
+        if self._grouped_ok():
+            return self.forward_grouped(hidden_states)
         if hidden_states.shape[0] < self.ROUTED_MIN_TOKENS:
             return self.forward_dense(hidden_states)
         return self.forward_routed(hidden_states)
+
+    def _grouped_ok(self) -> bool:
+        e = self.experts[self.expert_indicies[0]]
+        return e.w13.quant == "awq" and e.w13.qweight.shape[0] % 64 == 0 and \
+            e.w2.qweight.shape[0] % 64 == 0
+
+    def _stacked(self):
+        """k-packed weights of the local experts back to back (made once)."""
+        st = getattr(self, "_stack", None)
+        if st is None:
+            def stack(which):
+                pw, pz, sc = [], [], []
+                for idx in self.expert_indicies:
+                    lin = getattr(self.experts[idx], which)
+                    packed = getattr(lin, "_k_packed", None)
+                    if packed is None:
+                        packed = ops.awq_repack(lin.qweight, lin.qzeros)
+                    pw.append(packed[0])
+                    pz.append(packed[1])
+                    sc.append(lin.scales.data)
+                return torch.stack(pw).contiguous(), torch.stack(pz).contiguous(), torch.stack(sc).contiguous()
+            st = self._stack = (stack("w13"), stack("w2"))
+            # local index of every global expert; experts of other ranks share one trailing bucket
+            lut = torch.full((self.num_total_experts, ), len(self.expert_indicies), dtype=torch.int64)
+            for li, idx in enumerate(self.expert_indicies):
+                lut[idx] = li
+            self._local_of = lut.to(self.gate.device)
+        return st
+
+    def forward_grouped(self, hidden_states: torch.Tensor) -> torch.Tensor:
+        """AWQ experts, any batch: the (token, expert) pairs are sorted by expert on the device and
+        every local expert's rows go through ONE grouped GEMM launch per projection -- no host
+        synchronisation (graph-capturable) and no work on tokens an expert was not chosen for."""
+        num_tokens, hidden_dim = hidden_states.shape
+        (w13, w2) = self._stacked()
+        n_local = len(self.expert_indicies)
+        routing_weights, selected_experts = self.route(hidden_states)
+        local = self._local_of[selected_experts.reshape(-1)]             # [T * top_k]
+        order = torch.argsort(local, stable=True)
+        # (bincount would synchronise to size its result)
+        counts = (local.unsqueeze(1) == torch.arange(n_local, device=local.device)).sum(0)
+        offsets = torch.zeros(n_local + 1, dtype=torch.int32, device=local.device)
+        offsets[1:] = torch.cumsum(counts, 0)
+        token = torch.div(order, self.top_k, rounding_mode="floor")
+        xs = hidden_states.index_select(0, token)
+        rows = xs.shape[0]
+        h = ops.q4_gemm_grouped(xs, w13[0], w13[1], w13[2], offsets, 0, rows)
+        h = self.experts[self.expert_indicies[0]].act_fn(h)
+        y = ops.q4_gemm_grouped(h, w2[0], w2[1], w2[2], offsets, 0, rows)
+        y.mul_(routing_weights.reshape(-1)[order].unsqueeze(1))           # fp32 product, fp16 store
+        final = torch.zeros_like(hidden_states)
+        final.index_add_(0, token, y)      # rows of other ranks' experts are zero
+        return tensor_model_parallel_all_reduce(final).view(num_tokens, hidden_dim)
 
     def forward_routed(self, hidden_states: torch.Tensor) -> torch.Tensor:
         num_tokens, hidden_dim = hidden_states.shape
