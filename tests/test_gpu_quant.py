@@ -244,3 +244,32 @@ def test_awq_packed_gemm_mixtral_tp2_expert_shapes(ops, k, n):
     want = O.gemm_f16(x, O.awq_dequantize(qw, sc, qz))
     np.testing.assert_allclose(got.float().cpu().numpy(), O.from_bits(want, O.DT_F16), rtol=3e-3,
                                atol=8e-3)
+
+
+@pytest.mark.parametrize("ic,oc", [(512, 256), (1024, 4096), (2048, 320)])
+@pytest.mark.parametrize("counts,tail", [([5, 0, 70, 1], 0), ([64, 64, 64, 64], 0), ([0, 0, 130, 3], 9),
+                                         ([1, 1, 1, 1], 4)])
+def test_grouped_gemm_matches_per_set_products(ops, ic, oc, counts, tail):
+    """Several weight sets in one launch (an MoE block's experts): every row block equals the
+    oracle's product with its own set; empty sets are fine; rows behind the last set (tokens
+    routed to another rank's experts) come back zero."""
+    rng = np.random.default_rng(ic + sum(counts))
+    group, sets = 128, len(counts)
+    ws = [_awq_weights(rng, ic, oc, group) for _ in range(sets)]
+    packed = [ops.awq_repack(_cuda(qw), _cuda(qz)) for qw, qz, _ in ws]
+    pw = torch.stack([p[0] for p in packed]).contiguous()
+    pz = torch.stack([p[1] for p in packed]).contiguous()
+    sc = torch.stack([_cuda(w[2], O.DT_F16) for w in ws]).contiguous()
+    rows = sum(counts) + tail
+    x = O.to_bits(rng.uniform(-1, 1, (rows, ic)).astype(np.float32), O.DT_F16)
+    offsets = torch.tensor(np.concatenate([[0], np.cumsum(counts)]), dtype=torch.int32, device="cuda")
+    got = ops.q4_gemm_grouped(_cuda(x, O.DT_F16), pw, pz, sc, offsets, 0, rows)
+    torch.cuda.synchronize()
+    got = got.float().cpu().numpy()
+    start = 0
+    for (qw, qz, s), c in zip(ws, counts):
+        if c:
+            want = O.gemm_f16(x[start:start + c], O.awq_dequantize(qw, s, qz))
+            np.testing.assert_allclose(got[start:start + c], O.from_bits(want, O.DT_F16), rtol=3e-3, atol=4e-3)
+        start += c
+    assert not got[start:].any()
