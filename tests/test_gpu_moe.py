@@ -46,3 +46,45 @@ def test_routed_moe_matches_dense_loop_and_oracle(tokens):
         wt = (rw_c * (sel_c == ei)).sum(-1, keepdims=True)
         want += O.from_bits(O.to_bits(O.from_bits(h, O.DT_F16) * wt, O.DT_F16), O.DT_F16)
     np.testing.assert_allclose(routed.float().cpu().numpy(), want, rtol=1e-2, atol=1e-2)
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_moe_tensor_parallel_matches_single_rank(world, tmp_path):
+    """Experts split over ranks (np.array_split as in mixtral_quant.py:109-113), one all-reduce:
+    the sum over ranks equals the single-rank block.  Ranks are processes on the one GPU with
+    Gloo collectives; tokens routed to another rank's experts fall into the grouped launch's
+    trailing bucket and must contribute zeros."""
+    import os
+    import socket
+    import subprocess
+    import sys
+    from vllm_legacy_amd.model.mixtral_moe import QuantMixtralMoE
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / "moe_tp.npz")
+    here = os.path.dirname(os.path.abspath(__file__))
+    procs = [subprocess.Popen([sys.executable, "-u", os.path.join(here, "moe_tp_worker.py"), str(r), str(world),
+                               str(port), out], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+             for r in range(world)]
+    try:
+        res = [p.communicate(timeout=100) + (p.returncode, ) for p in procs]
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    for so, se, rc in res:
+        assert rc == 0, se[-3000:]
+    z = np.load(out)
+    assert len(z["local"]) == 8 // world
+    moe = QuantMixtralMoE(512, 1024, 8, 2, "awq", 128, "cuda", seed=1)
+    for e in moe.experts:
+        for lin in (e.w13, e.w2):
+            lin.scales.data = (lin.scales.data.float() * 0.3).half()
+    g = torch.Generator(device="cuda").manual_seed(99)
+    x = torch.empty((96, 512), device="cuda").normal_(0, 1, generator=g).half()
+    with torch.inference_mode():
+        want = moe.forward_dense(x).float().cpu().numpy()
+    # partial sums are rounded to fp16 per rank before the all-reduce: a few fp16 ulps
+    np.testing.assert_allclose(z["grouped"], want, atol=8e-3, rtol=8e-3)
+    np.testing.assert_allclose(z["dense"], want, atol=8e-3, rtol=8e-3)
