@@ -27,6 +27,11 @@ def main():
         grouped = moe.forward_grouped(x)
         dense = moe.forward_dense(x)
     torch.cuda.synchronize()
+    xg = ps.get_tp_xgmi_all_reduce(torch.device("cuda", 0))
+    if os.environ.get("VLA_XGMI_ALLREDUCE") == "1":
+        assert xg is not None and not xg.disabled and xg.error_count() == 0
+    else:
+        assert xg is None
     if rank == 0:
         np.savez(out_path, grouped=grouped.float().cpu().numpy(), dense=dense.float().cpu().numpy(),
                  local=np.array(moe.expert_indicies))

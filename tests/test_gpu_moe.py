@@ -48,12 +48,13 @@ def test_routed_moe_matches_dense_loop_and_oracle(tokens):
     np.testing.assert_allclose(routed.float().cpu().numpy(), want, rtol=1e-2, atol=1e-2)
 
 
-@pytest.mark.parametrize("world", [2, 4])
-def test_moe_tensor_parallel_matches_single_rank(world, tmp_path):
+@pytest.mark.parametrize("world,xgmi", [(2, False), (4, False), (2, True)])
+def test_moe_tensor_parallel_matches_single_rank(world, xgmi, tmp_path):
     """Experts split over ranks (np.array_split as in mixtral_quant.py:109-113), one all-reduce:
     the sum over ranks equals the single-rank block.  Ranks are processes on the one GPU with
     Gloo collectives; tokens routed to another rank's experts fall into the grouped launch's
-    trailing bucket and must contribute zeros."""
+    trailing bucket and must contribute zeros.  xgmi: the all-reduce goes through the peer-memory
+    communicator that communication_op creates on first use under VLA_XGMI_ALLREDUCE=1."""
     import os
     import socket
     import subprocess
@@ -65,7 +66,9 @@ def test_moe_tensor_parallel_matches_single_rank(world, tmp_path):
     out = str(tmp_path / "moe_tp.npz")
     here = os.path.dirname(os.path.abspath(__file__))
     procs = [subprocess.Popen([sys.executable, "-u", os.path.join(here, "moe_tp_worker.py"), str(r), str(world),
-                               str(port), out], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+                               str(port), out], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                              env=dict(os.environ, VLA_XGMI_ALLREDUCE="1" if xgmi else "0",
+                                       HSA_ENABLE_IPC_MODE_LEGACY="0"))
              for r in range(world)]
     try:
         res = [p.communicate(timeout=100) + (p.returncode, ) for p in procs]
