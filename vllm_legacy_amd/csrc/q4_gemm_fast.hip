@@ -654,7 +654,11 @@ extern "C" int vla_q4_gemm_grouped(const void* x, const int32_t* qweight, const 
     splits = 1;
   Q4Groups gp;
   gp.row_offsets = row_offsets;
-  gp.tiles_per_set = (max_rows_per_set + 63) / 64;
+  // 64-row tiles for decode-sized sets, 128-row tiles once the average set fills them
+  // (measured on Mixtral shapes: 256 rows per set 1.25 ms with 64-row tiles, 1.31 with 128-row
+  // ones; 1024 rows per set 4.26 against 3.99)
+  const int mt = total_rows / num_sets >= 384 ? 4 : 2;
+  gp.tiles_per_set = (max_rows_per_set + 32 * mt - 1) / (32 * mt);
   gp.total_rows = total_rows;
   gp.w_stride = (int64_t)(k / 8) * n;
   gp.z_stride = (int64_t)(k / group) * (n / 8);
@@ -667,16 +671,25 @@ extern "C" int vla_q4_gemm_grouped(const void* x, const int32_t* qweight, const 
     // rows of sets that got fewer rows than a tile are never written: the sum must not see junk
     VLA_HIP_CHECK(hipMemsetAsync(workspace, 0, (size_t)need, s));
   }
+#define VLA_Q4G_ARGS                                                                            \
+  (const _Float16*)x, (const uint32_t*)qweight, (const uint32_t*)qzeros, (const _Float16*)scales, \
+      dst, 0, n, k, group, kps, gp
 #define VLA_Q4G(Z, SP)                                                                          \
-  hipLaunchKernelGGL((q4_gemm_m32_kernel<Z, SP, 4, 2, true>), grid, dim3(256), 0, s,            \
-                     (const _Float16*)x, (const uint32_t*)qweight, (const uint32_t*)qzeros,     \
-                     (const _Float16*)scales, dst, 0, n, k, group, kps, gp)
+  do {                                                                                          \
+    if (mt == 4)                                                                                \
+      hipLaunchKernelGGL((q4_gemm_m32_kernel<Z, SP, 4, 4, true>), grid, dim3(256), 0, s,        \
+                         VLA_Q4G_ARGS);                                                         \
+    else                                                                                        \
+      hipLaunchKernelGGL((q4_gemm_m32_kernel<Z, SP, 4, 2, true>), grid, dim3(256), 0, s,        \
+                         VLA_Q4G_ARGS);                                                         \
+  } while (0)
   if (zero_offset == 0) {
     if (splits > 1) VLA_Q4G(0, true); else VLA_Q4G(0, false);
   } else {
     if (splits > 1) VLA_Q4G(1, true); else VLA_Q4G(1, false);
   }
 #undef VLA_Q4G
+#undef VLA_Q4G_ARGS
   VLA_HIP_CHECK(hipGetLastError());
   if (splits > 1) {
     const int64_t elems = (int64_t)total_rows * n;
