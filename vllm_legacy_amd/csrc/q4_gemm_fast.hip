@@ -303,6 +303,13 @@ __global__ __launch_bounds__(64 * NW) void q4_gemm_m32_kernel(
     for (int i = 0; i < 16; ++i) acc[a][i] = 0.f;
 
   const f16x2 sixteenth = {(_Float16)0.0625f, (_Float16)0.0625f};
+  // (w & mask) | 0x6400.. as ONE v_and_or_b32: the instruction takes a single scalar or literal
+  // operand, so the exponent pattern has to sit in a vector register the compiler cannot fold
+  // back into a literal (it would split the operation into v_and + v_or)
+  uint32_t c1024 = 0x64006400u;
+  asm volatile("" : "+v"(c1024));
+  constexpr uint32_t kLoMask = 0x000f000fu, kHiMask = 0x00f000f0u;
+  auto and_or = [](uint32_t a, uint32_t m, uint32_t c) { return (a & m) | c; };
 
   // One K step t: issue the loads of x(t+2) into `xnew` and of the weights of step t+3 into
   // `wnew`, compute step t from `wcur` and LDS buffer t & 1, then park x(t+1) (`xpark`, loaded
@@ -331,12 +338,10 @@ __global__ __launch_bounds__(64 * NW) void q4_gemm_m32_kernel(
     };
     auto dequant = [&](int s) {
       const uint32_t w = wcur.w[s], w8 = w >> 8;
-      const f16x2 d0 = as_h2((w & 0x000f000fu) | 0x64006400u) + zc1;
-      const f16x2 d1 = __builtin_elementwise_fma(as_h2((w & 0x00f000f0u) | 0x64006400u),
-                                                 sixteenth, zc2);
-      const f16x2 d2 = as_h2((w8 & 0x000f000fu) | 0x64006400u) + zc1;
-      const f16x2 d3 = __builtin_elementwise_fma(as_h2((w8 & 0x00f000f0u) | 0x64006400u),
-                                                 sixteenth, zc2);
+      const f16x2 d0 = as_h2(and_or(w, kLoMask, c1024)) + zc1;
+      const f16x2 d1 = __builtin_elementwise_fma(as_h2(and_or(w, kHiMask, c1024)), sixteenth, zc2);
+      const f16x2 d2 = as_h2(and_or(w8, kLoMask, c1024)) + zc1;
+      const f16x2 d3 = __builtin_elementwise_fma(as_h2(and_or(w8, kHiMask, c1024)), sixteenth, zc2);
       u32x4 bf;
       bf[0] = as_u32(d0 * sc2);
       bf[1] = as_u32(d1 * sc2);
