@@ -11,6 +11,21 @@ from tests import pa_testlib as T
 pytestmark = pytest.mark.gpu
 
 
+def test_gptq_experts_take_the_grouped_path():
+    from vllm_legacy_amd.model.mixtral_moe import QuantMixtralMoE
+    moe = QuantMixtralMoE(512, 1024, 8, 2, "gptq", 128, "cuda", seed=2)
+    for e in moe.experts:
+        for lin in (e.w13, e.w2):
+            lin.scales.data = (lin.scales.data.float() * 0.3).half()
+    assert moe._grouped_ok()
+    g = torch.Generator(device="cuda").manual_seed(5)
+    x = torch.empty((100, 512), device="cuda").normal_(0, 1, generator=g).half()
+    with torch.inference_mode():
+        grouped = moe.forward_grouped(x)
+        dense = moe.forward_dense(x)
+    torch.testing.assert_close(grouped.float(), dense.float(), atol=4e-3, rtol=4e-3)
+
+
 @pytest.mark.parametrize("tokens", [1, 37, 256, 700])
 def test_routed_moe_matches_dense_loop_and_oracle(tokens):
     from vllm_legacy_amd.model.mixtral_moe import QuantMixtralMoE

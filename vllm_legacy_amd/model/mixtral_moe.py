@@ -10,7 +10,7 @@ the end.  Two things differ in execution, not in values:
   (gather -> w13 GEMM -> SiLU*mul -> w2 GEMM -> weighted scatter-add), 1/4 of the GEMM work at
   top-2 of 8.  Adding the skipped zero contributions would not change any element, and the
   per-token accumulation order (ascending expert index) is the reference's.
-* With AWQ experts the per-expert loop is one grouped GEMM launch per projection over rows sorted
+* The per-expert loop is one grouped GEMM launch per projection over rows sorted
   by expert on the device (forward_grouped): no host synchronisation, graph-capturable.
 * w1 and w3 are stored side by side as one [hidden, 2*ffn] int4 matrix so that one GEMM feeds the
   fused SiLU*mul kernel (the reference's TODO at :82).
@@ -77,8 +77,9 @@ class QuantMixtralMoE(nn.Module):
         routing_weights /= routing_weights.sum(dim=-1, keepdim=True)
         return routing_weights, selected_experts
 
-    # GPTQ experts (no grouped launch yet): below this many tokens the per-expert gather of
-    # forward_routed (host-synchronising) costs more than it saves and the dense loop is used
+    # experts the grouped launch does not take (GPTQ with activation reordering): below this many
+    # tokens the per-expert gather of forward_routed (host-synchronising) costs more than it
+    # saves and the dense loop is used
     ROUTED_MIN_TOKENS = 512
 
     def forward(self, hidden_states: torch.Tensor) -> torch.Tensor:
@@ -89,21 +90,37 @@ class QuantMixtralMoE(nn.Module):
         return self.forward_routed(hidden_states)
 
     def _grouped_ok(self) -> bool:
+        """The grouped launch takes k-packed 4-bit weights: AWQ after its re-layout, GPTQ after the
+        exllama shuffle without activation reordering (g_idx would permute rows per expert)."""
         e = self.experts[self.expert_indicies[0]]
-        return e.w13.quant == "awq" and e.w13.qweight.shape[0] % 64 == 0 and \
-            e.w2.qweight.shape[0] % 64 == 0
+        if e.w13.quant == "awq":
+            return e.w13.qweight.shape[0] % 64 == 0 and e.w2.qweight.shape[0] % 64 == 0
+        if e.w13.quant == "gptq":
+            cfg = e.w13.method.quant_config
+            return cfg.weight_bits == 4 and not cfg.desc_act and cfg.group_size % 64 == 0
+        return False
 
     def _stacked(self):
         """k-packed weights of the local experts back to back (made once)."""
         st = getattr(self, "_stack", None)
         if st is None:
+            gptq = self.experts[self.expert_indicies[0]].w13.quant == "gptq"
+            self._zero_offset = 1 if gptq else 0
+
             def stack(which):
                 pw, pz, sc = [], [], []
                 for idx in self.expert_indicies:
                     lin = getattr(self.experts[idx], which)
-                    packed = getattr(lin, "_k_packed", None)
-                    if packed is None:
-                        packed = ops.awq_repack(lin.qweight, lin.qzeros)
+                    if gptq:
+                        # one tiny product runs the method's first-use shuffle (gptq.py:209-217)
+                        lin.method.apply(lin, torch.zeros((1, lin.qweight.shape[0] * 8),
+                                                          dtype=lin.scales.dtype,
+                                                          device=lin.scales.device))
+                        packed = (lin.qweight.data, lin.qzeros.data)
+                    else:
+                        packed = getattr(lin, "_k_packed", None)
+                        if packed is None:
+                            packed = ops.awq_repack(lin.qweight, lin.qzeros)
                     pw.append(packed[0])
                     pz.append(packed[1])
                     sc.append(lin.scales.data)
@@ -117,7 +134,7 @@ class QuantMixtralMoE(nn.Module):
         return st
 
     def forward_grouped(self, hidden_states: torch.Tensor) -> torch.Tensor:
-        """AWQ experts, any batch: the (token, expert) pairs are sorted by expert on the device and
+        """The (token, expert) pairs are sorted by expert on the device and
         every local expert's rows go through ONE grouped GEMM launch per projection -- no host
         synchronisation (graph-capturable) and no work on tokens an expert was not chosen for."""
         num_tokens, hidden_dim = hidden_states.shape
@@ -133,9 +150,10 @@ class QuantMixtralMoE(nn.Module):
         token = torch.div(order, self.top_k, rounding_mode="floor")
         xs = hidden_states.index_select(0, token)
         rows = xs.shape[0]
-        h = ops.q4_gemm_grouped(xs, w13[0], w13[1], w13[2], offsets, 0, rows)
+        zo = self._zero_offset
+        h = ops.q4_gemm_grouped(xs, w13[0], w13[1], w13[2], offsets, zo, rows)
         h = self.experts[self.expert_indicies[0]].act_fn(h)
-        y = ops.q4_gemm_grouped(h, w2[0], w2[1], w2[2], offsets, 0, rows)
+        y = ops.q4_gemm_grouped(h, w2[0], w2[1], w2[2], offsets, zo, rows)
         y.mul_(routing_weights.reshape(-1)[order].unsqueeze(1))           # fp32 product, fp16 store
         final = torch.zeros_like(hidden_states)
         final.index_add_(0, token, y)      # rows of other ranks' experts are zero
