@@ -507,6 +507,10 @@ static Q4Shape pick_shape(int m, int n, int k, int group) {
     want = 256 / wgs;
     if (want > 8) want = 8;
     if (want > k / (8 * TK)) want = k / (8 * TK);
+    if (const char* e = getenv("VLA_Q4_MAXSPLIT")) {   // kernel studies
+      const int cap = atoi(e);
+      if (cap >= 1 && want > cap) want = cap;
+    }
   }
   if (want < 1) want = 1;
   if (const char* e = getenv("VLA_Q4_TUNE")) {
