@@ -168,14 +168,16 @@ __global__ __launch_bounds__(PF_THREADS, D == 112 ? 1 : 2) void prefill_attentio
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int h = lane >> 5, c = lane & 31;
-  const int head = blockIdx.y, seq = blockIdx.z;
+  // grid = (heads, sequences, query tiles): workgroups are handed out x-fastest, so all heads
+  // and sequences of one query tile go together -- the heads of a KV group side by side -- and
+  // the tiles with the longest key walks (the last ones) are handed out first
+  const int head = blockIdx.x, seq = blockIdx.y;
   const int kv_head = head / (p.num_heads / p.num_kv_heads);
   const int seq_start = p.cu_seqlens[seq];
   const int ctx = PREFIX ? p.ctx_lens[seq] : 0;
   // number of new tokens; positions are absolute: query i sits at ctx + i
   const int n_new = PREFIX ? p.seq_lens[seq] - ctx : p.cu_seqlens[seq + 1] - seq_start;
-  // the longest key walks (last query tiles) are dispatched first
-  const int q0 = (gridDim.x - 1 - blockIdx.x) * PF_BM;
+  const int q0 = (gridDim.z - 1 - blockIdx.z) * PF_BM;
   if (q0 >= n_new) return;
   // a window known to be absent at compile time keeps its tests out of the tile loop (5 % of
   // the kernel's time when left to run time)
@@ -517,13 +519,14 @@ extern "C" int vla_prefill_attention(void* out, const void* query, const void* k
   if ((query_stride | key_stride | value_stride | out_stride) % 8 || ((uintptr_t)query % 16) ||
       ((uintptr_t)key % 16) || ((uintptr_t)value % 16))
     return VLA_ERR_ARG;
+  if (num_seqs > 65535 || (max_seqlen + PF_BM - 1) / PF_BM > 65535) return VLA_ERR_ARG;  // grid y, z
   PrefillParams p{};
   p.out = out; p.q = query; p.k = key; p.v = value;
   p.cu_seqlens = cu_seqlens; p.alibi_slopes = alibi_slopes;
   p.num_heads = num_heads; p.num_kv_heads = num_kv_heads;
   p.q_stride = query_stride; p.k_stride = key_stride; p.v_stride = value_stride;
   p.out_stride = out_stride; p.scale = scale; p.sliding_window = 0;
-  dim3 grid((max_seqlen + PF_BM - 1) / PF_BM, num_heads, num_seqs);
+  dim3 grid(num_heads, num_seqs, (max_seqlen + PF_BM - 1) / PF_BM);
   pf_launch<false, false, false>(p, head_size, dtype, grid, (hipStream_t)stream);
   VLA_HIP_CHECK(hipGetLastError());
   return VLA_OK;
@@ -555,6 +558,7 @@ extern "C" int vla_prefix_prefill_attention(
       ((uintptr_t)key % 16) || ((uintptr_t)value % 16) || ((uintptr_t)key_cache % 16) ||
       ((uintptr_t)value_cache % 16) || (kv_block_stride * eb) % 16 || (kv_head_stride * eb) % 16)
     return VLA_ERR_ARG;
+  if (num_seqs > 65535 || (max_query_len + PF_BM - 1) / PF_BM > 65535) return VLA_ERR_ARG;  // grid y, z
   PrefillParams p{};
   p.out = out; p.q = query; p.k = key; p.v = value;
   p.cu_seqlens = query_start_loc; p.alibi_slopes = alibi_slopes;
@@ -566,7 +570,7 @@ extern "C" int vla_prefix_prefill_attention(
   p.seq_lens = seq_lens; p.ctx_lens = context_lens; p.max_blocks_per_seq = max_blocks_per_seq;
   p.log2_block_size = block_size == 8 ? 3 : block_size == 16 ? 4 : block_size == 32 ? 5 : 6;
   p.kv_block_stride = kv_block_stride; p.kv_head_stride = kv_head_stride; p.kv_scale = kv_scale;
-  dim3 grid((max_query_len + PF_BM - 1) / PF_BM, num_heads, num_seqs);
+  dim3 grid(num_heads, num_seqs, (max_query_len + PF_BM - 1) / PF_BM);
   hipStream_t s = (hipStream_t)stream;
   if (p.sliding_window > 0) {
     if (fp8) pf_launch<true, true, true>(p, head_size, dtype, grid, s);
