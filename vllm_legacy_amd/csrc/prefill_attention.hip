@@ -320,7 +320,9 @@ __global__ __launch_bounds__(PF_THREADS, D == 112 ? 1 : 2) void prefill_attentio
       }
     }
     __syncthreads();
-    // wave-uniform: every key follows every query of this wave, or lies before all their windows
+    // wave-uniform: the wave has no query at all (a short last tile), every key follows every
+    // query of this wave, or lies before all their windows
+    if (q0 + 32 * wave >= n_new) continue;
     if (kpos0 > wq_max) continue;
     if (W > 0 && wq_min - (kpos0 + PF_BN - 1) >= W) continue;
 
