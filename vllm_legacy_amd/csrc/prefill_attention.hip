@@ -96,13 +96,14 @@ struct PrefillParams {
 // 16-byte chunk swizzles of the LDS images (RB bytes per row):
 //   K image (row = key) and the transposed V image of cached blocks (row = dim), read by
 //            ds_read_b128 with rows on lanes: 256-byte rows chunk ^ (row & 15); 128-byte rows
-//            chunk ^ (row & 7) (the row parity picks the half of the bank row)
+//            chunk ^ ((row >> 1) & 7) -- two rows share a 256-byte bank line, the row parity
+//            picks its half, so 16 consecutive rows land on 16 distinct 16-byte slots
 //   V image (row = key), read by ds_read_b64_tr_b16 (8 keys x 32 bytes per half wave): 256-byte
 //            rows chunk ^ (((row & 3) << 2) | ((row >> 2) & 3)); 128-byte rows
 //            chunk ^ ((((row >> 1) & 1) << 1) | (((row >> 3) & 1) << 2))
 template <int DP>
 __device__ __forceinline__ int k_swz(int row, int ch) {
-  return DP == 128 ? (ch ^ (row & 15)) : (ch ^ (row & 7));
+  return DP == 128 ? (ch ^ (row & 15)) : (ch ^ ((row >> 1) & 7));
 }
 template <int DP>
 __device__ __forceinline__ int v_swz(int row, int ch) {
