@@ -96,14 +96,14 @@ def oracle_attention(c, version="v1", kv_scale=1.0, seq_subset=None):
                                 alibi_slopes=c.alibi, max_seq_len=int(c.seq_lens.max()))[0]
 
 
-def run_hip_attention(ops, c, version="v1", kv_scale=1.0):
+def run_hip_attention(ops, c, version="v1", kv_scale=1.0, seq_order=None):
     """Call the HIP op exactly as the reference test calls vllm._custom_ops
     (tests/kernels/test_attention.py:180-227)."""
     out = torch.empty_like(c.t_q)
     kvd = "fp8" if c.kv == O.KV_FP8 else "auto"
     if version == "v1":
         ops.paged_attention_v1(out, c.t_q, c.t_kc, c.t_vc, c.hkv, c.scale, c.t_bt, c.t_sl, c.bs,
-                               c.max_seq_len, c.t_alibi, kvd, kv_scale)
+                               c.max_seq_len, c.t_alibi, kvd, kv_scale, seq_order=seq_order)
     else:
         S, H, D = out.shape
         P = (c.max_seq_len + 511) // 512
@@ -111,7 +111,8 @@ def run_hip_attention(ops, c, version="v1", kv_scale=1.0):
         es = torch.empty((S, H, P), dtype=torch.float32, device=out.device)
         ml = torch.empty_like(es)
         ops.paged_attention_v2(out, es, ml, tmp, c.t_q, c.t_kc, c.t_vc, c.hkv, c.scale, c.t_bt,
-                               c.t_sl, c.bs, c.max_seq_len, c.t_alibi, kvd, kv_scale)
+                               c.t_sl, c.bs, c.max_seq_len, c.t_alibi, kvd, kv_scale,
+                               seq_order=seq_order)
     torch.cuda.synchronize()
     return out
 

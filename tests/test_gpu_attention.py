@@ -346,3 +346,20 @@ def test_blocksparse_attention(ops, version, kv_fp8, params, dt):
             p = np.exp(logits - logits.max())
             ref = (p / p.sum()) @ v[m, h // (c.hq // c.hkv), :]
             np.testing.assert_allclose(got[s, h], ref, atol=3 * atol, rtol=1e-3)
+
+
+@pytest.mark.parametrize("version", ["v1", "v2"])
+@pytest.mark.parametrize("head_size,block_size", [(128, 16), (112, 8)])   # MFMA and generic kernel
+def test_sequence_order_does_not_change_results(ops, version, head_size, block_size):
+    """seq_order only says which grid row takes which sequence: with the longest-first order
+    of make_seq_order, and with an arbitrary permutation, every output bit stays the same."""
+    c = T.make_attention_case(21, 33, (8, 2), head_size, block_size, O.DT_F16, head_size == 128,
+                              False, 1500)
+    base = T.run_hip_attention(ops, c, version)
+    order = ops.make_seq_order(c.t_sl)
+    lens = c.t_sl.cpu().numpy()
+    assert sorted(order.cpu().tolist()) == list(range(33))
+    assert (np.diff(lens[order.cpu().numpy()]) <= 0).all()
+    for o in (order, torch.randperm(33, device="cuda").to(torch.int32)):
+        got = T.run_hip_attention(ops, c, version, seq_order=o)
+        assert torch.equal(got.view(torch.int16), base.view(torch.int16))

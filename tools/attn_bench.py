@@ -29,6 +29,8 @@ def main():
     ap.add_argument("--layers", type=int, default=2)
     ap.add_argument("--version", default="v1")
     ap.add_argument("--ragged", action="store_true", help="sequence lengths U(1, seq)")
+    ap.add_argument("--sorted", action="store_true", help="with --ragged: longest sequences first")
+    ap.add_argument("--order", action="store_true", help="pass ops.make_seq_order(seq_lens) to the kernel")
     ap.add_argument("--block", type=int, default=16)
     ap.add_argument("--head-size", type=int, default=128)
     ap.add_argument("--generic", action="store_true", help="force the coverage kernel")
@@ -63,6 +65,8 @@ def main():
     bt = torch.randperm(nb, generator=g, device=dev).to(torch.int32).view(B, S // BS).contiguous()
     if a.ragged:
         sl = torch.randint(1, S + 1, (B, ), generator=g, device=dev, dtype=torch.int32)
+        if a.sorted:
+            sl = torch.sort(sl, descending=True).values.contiguous()
     else:
         sl = torch.full((B, ), S, dtype=torch.int32, device=dev)
     P = (S + 511) // 512
@@ -70,13 +74,14 @@ def main():
     es = torch.empty((B, a.hq, P), dtype=torch.float32, device=dev)
     ml = torch.empty_like(es)
     kvd = "fp8" if fp8 else "auto"
+    order = ops.make_seq_order(sl) if a.order else None
 
     def run(i):
         kc, vc = caches[i % a.layers]
         if a.version == "v1":
-            ops.paged_attention_v1(out, q, kc, vc, a.hkv, scale, bt, sl, BS, S, None, kvd, 1.0)
+            ops.paged_attention_v1(out, q, kc, vc, a.hkv, scale, bt, sl, BS, S, None, kvd, 1.0, seq_order=order)
         else:
-            ops.paged_attention_v2(out, es, ml, tmp, q, kc, vc, a.hkv, scale, bt, sl, BS, S, None, kvd, 1.0)
+            ops.paged_attention_v2(out, es, ml, tmp, q, kc, vc, a.hkv, scale, bt, sl, BS, S, None, kvd, 1.0, seq_order=order)
 
     for i in range(3):
         run(i)

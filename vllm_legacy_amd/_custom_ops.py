@@ -98,6 +98,19 @@ def fused_add_rms_norm(input: torch.Tensor, residual: torch.Tensor, weight: torc
 # ---------------------------------------------------------------- paged attention
 
 
+def make_seq_order(seq_lens: torch.Tensor) -> torch.Tensor:
+    """The launch order that takes the longest sequences first (int32 permutation; two small
+    device kernels, no synchronisation).  Worth computing once per step for a ragged decode
+    batch and sharing between the layers."""
+    return torch.argsort(seq_lens, descending=True, stable=True).to(torch.int32)
+
+
+def _check_seq_order(seq_order, num_seqs: int) -> None:
+    if seq_order is not None:
+        assert seq_order.dtype == torch.int32 and seq_order.is_contiguous()
+        assert seq_order.numel() == num_seqs
+
+
 def paged_attention_v1(
     out: torch.Tensor,
     query: torch.Tensor,
@@ -117,13 +130,16 @@ def paged_attention_v1(
     blocksparse_vert_stride: int = 0,
     blocksparse_block_size: int = 64,
     blocksparse_head_sliding_step: int = 0,
+    seq_order: Optional[torch.Tensor] = None,
 ) -> None:
+    """seq_order (not in the reference): int32 [num_seqs] permutation, the order in which the
+    launch takes the sequences -- longest first evens out a ragged batch (make_seq_order)."""
     paged_attention_v1_raw(out, query, key_cache.data_ptr(), key_cache.stride(0),
                            key_cache.stride(1), value_cache.data_ptr(), num_kv_heads, scale,
                            block_tables, seq_lens, block_size, max_seq_len, alibi_slopes,
                            kv_cache_dtype, kv_scale, tp_rank, blocksparse_local_blocks,
                            blocksparse_vert_stride, blocksparse_block_size,
-                           blocksparse_head_sliding_step)
+                           blocksparse_head_sliding_step, seq_order)
 
 
 def paged_attention_v1_raw(out, query, key_cache_ptr: int, kv_block_stride: int,
@@ -131,21 +147,22 @@ def paged_attention_v1_raw(out, query, key_cache_ptr: int, kv_block_stride: int,
                            block_tables, seq_lens, block_size, max_seq_len, alibi_slopes,
                            kv_cache_dtype, kv_scale, tp_rank=0, blocksparse_local_blocks=0,
                            blocksparse_vert_stride=0, blocksparse_block_size=64,
-                           blocksparse_head_sliding_step=0) -> None:
-    _require_cuda(out, query, block_tables, seq_lens, alibi_slopes)
+                           blocksparse_head_sliding_step=0, seq_order=None) -> None:
+    _require_cuda(out, query, block_tables, seq_lens, alibi_slopes, seq_order)
     num_seqs, num_heads, head_size = query.shape
+    _check_seq_order(seq_order, num_seqs)
     assert out.is_contiguous() and query.stride(1) == head_size and query.stride(2) == 1
     assert block_tables.dtype == torch.int32 and seq_lens.dtype == torch.int32
     assert block_tables.stride(1) == 1
     with torch.cuda.device(query.device):
-        check(_lib.lib().vla_paged_attention_v1(
+        check(_lib.lib().vla_paged_attention_v1_ordered(
             out.data_ptr(), query.data_ptr(), key_cache_ptr, value_cache_ptr, num_seqs, num_heads,
             num_kv_heads, head_size, block_size, scale, block_tables.data_ptr(),
             seq_lens.data_ptr(), block_tables.stride(0), max_seq_len, _ptr(alibi_slopes),
             query.stride(0), kv_block_stride, kv_head_stride, _dt(query),
             _lib.kv_dtype_code(kv_cache_dtype), kv_scale, tp_rank, blocksparse_local_blocks,
             blocksparse_vert_stride, blocksparse_block_size, blocksparse_head_sliding_step,
-            _stream(query.device)), "paged_attention_v1")
+            _ptr(seq_order), _stream(query.device)), "paged_attention_v1")
 
 
 def paged_attention_v2(
@@ -170,13 +187,14 @@ def paged_attention_v2(
     blocksparse_vert_stride: int = 0,
     blocksparse_block_size: int = 64,
     blocksparse_head_sliding_step: int = 0,
+    seq_order: Optional[torch.Tensor] = None,
 ) -> None:
     paged_attention_v2_raw(out, exp_sum, max_logits, tmp_out, query, key_cache.data_ptr(),
                            key_cache.stride(0), key_cache.stride(1), value_cache.data_ptr(),
                            num_kv_heads, scale, block_tables, seq_lens, block_size, max_seq_len,
                            alibi_slopes, kv_cache_dtype, kv_scale, tp_rank,
                            blocksparse_local_blocks, blocksparse_vert_stride,
-                           blocksparse_block_size, blocksparse_head_sliding_step)
+                           blocksparse_block_size, blocksparse_head_sliding_step, seq_order)
 
 
 def paged_attention_v2_raw(out, exp_sum, max_logits, tmp_out, query, key_cache_ptr: int,
@@ -184,9 +202,12 @@ def paged_attention_v2_raw(out, exp_sum, max_logits, tmp_out, query, key_cache_p
                            num_kv_heads, scale, block_tables, seq_lens, block_size, max_seq_len,
                            alibi_slopes, kv_cache_dtype, kv_scale, tp_rank=0,
                            blocksparse_local_blocks=0, blocksparse_vert_stride=0,
-                           blocksparse_block_size=64, blocksparse_head_sliding_step=0) -> None:
-    _require_cuda(out, exp_sum, max_logits, tmp_out, query, block_tables, seq_lens, alibi_slopes)
+                           blocksparse_block_size=64, blocksparse_head_sliding_step=0,
+                           seq_order=None) -> None:
+    _require_cuda(out, exp_sum, max_logits, tmp_out, query, block_tables, seq_lens, alibi_slopes,
+                  seq_order)
     num_seqs, num_heads, head_size = query.shape
+    _check_seq_order(seq_order, num_seqs)
     num_partitions = (max_seq_len + _lib.PARTITION_SIZE - 1) // _lib.PARTITION_SIZE
     assert out.is_contiguous() and query.stride(1) == head_size and query.stride(2) == 1
     assert exp_sum.is_contiguous() and max_logits.is_contiguous() and tmp_out.is_contiguous()
@@ -197,15 +218,15 @@ def paged_attention_v2_raw(out, exp_sum, max_logits, tmp_out, query, key_cache_p
     assert block_tables.dtype == torch.int32 and seq_lens.dtype == torch.int32
     assert block_tables.stride(1) == 1
     with torch.cuda.device(query.device):
-        check(_lib.lib().vla_paged_attention_v2(
+        check(_lib.lib().vla_paged_attention_v2_ordered(
             out.data_ptr(), exp_sum.data_ptr(), max_logits.data_ptr(), tmp_out.data_ptr(),
             query.data_ptr(), key_cache_ptr, value_cache_ptr, num_seqs, num_heads, num_kv_heads,
             head_size, block_size, scale, block_tables.data_ptr(), seq_lens.data_ptr(),
             block_tables.stride(0), max_seq_len, _ptr(alibi_slopes), query.stride(0),
             kv_block_stride, kv_head_stride, _dt(query), _lib.kv_dtype_code(kv_cache_dtype),
             kv_scale, tp_rank, blocksparse_local_blocks, blocksparse_vert_stride,
-            blocksparse_block_size, blocksparse_head_sliding_step, _stream(query.device)),
-            "paged_attention_v2")
+            blocksparse_block_size, blocksparse_head_sliding_step, _ptr(seq_order),
+            _stream(query.device)), "paged_attention_v2")
 
 
 def prefill_attention(out: torch.Tensor, query: torch.Tensor, key: torch.Tensor,

@@ -22,6 +22,7 @@ _lib = None
 EXPORTS = [
     "vla_status_string", "vla_last_hip_error", "vla_abi_version", "vla_set_attention_path",
     "vla_kv_dtype_from_string", "vla_paged_attention_v1", "vla_paged_attention_v2",
+    "vla_paged_attention_v1_ordered", "vla_paged_attention_v2_ordered",
     "vla_reshape_and_cache", "vla_copy_blocks", "vla_swap_blocks", "vla_convert_fp8",
     "vla_awq_dequantize", "vla_awq_gemm", "vla_gptq_dequantize", "vla_gptq_gemm",
     "vla_gptq_shuffle", "vla_get_max_shared_memory_per_block", "vla_awq_repack",
@@ -60,6 +61,11 @@ def lib():
                                              i64, i64, i, i, f, i, i, i, i, i, p]
         L.vla_paged_attention_v2.argtypes = [p, p, p, p, p, p, p, i, i, i, i, i, f, p, p, i, i,
                                              p, i64, i64, i64, i, i, f, i, i, i, i, i, p]
+        L.vla_paged_attention_v1_ordered.argtypes = [p, p, p, p, i, i, i, i, i, f, p, p, i, i, p,
+                                                     i64, i64, i64, i, i, f, i, i, i, i, i, p, p]
+        L.vla_paged_attention_v2_ordered.argtypes = [p, p, p, p, p, p, p, i, i, i, i, i, f, p, p,
+                                                     i, i, p, i64, i64, i64, i, i, f, i, i, i, i,
+                                                     i, p, p]
         L.vla_reshape_and_cache.argtypes = [p, p, p, p, p, i, i, i, i, i, i64, i64, i, i, f, p]
         L.vla_copy_blocks.argtypes = [p, p, i, p, i, i64, p]
         L.vla_swap_blocks.argtypes = [p, p, p, i, i64, i, p]

@@ -60,6 +60,10 @@ class Gfx950PagedAttentionMetadata(AttentionMetadata, PagedAttentionMetadata):
     context_lens_tensor: Optional[torch.Tensor]
     _cached_prefill_metadata: Optional["Gfx950PagedAttentionMetadata"] = None
     _cached_decode_metadata: Optional["Gfx950PagedAttentionMetadata"] = None
+    # not in the reference: the order in which the decode kernels take the decode sequences
+    # (ops.make_seq_order of their lengths: longest first), computed once per step by whoever
+    # builds the metadata and shared by all layers; None = batch order
+    decode_seq_order: Optional[torch.Tensor] = None
 
     @property
     def prefill_metadata(self) -> Optional["Gfx950PagedAttentionMetadata"]:
@@ -90,7 +94,7 @@ class Gfx950PagedAttentionMetadata(AttentionMetadata, PagedAttentionMetadata):
                 max_prefill_seq_len=0, max_decode_seq_len=self.max_decode_seq_len,
                 query_start_loc=None, seq_start_loc=None, context_lens_tensor=None,
                 block_tables=self.block_tables[self.num_prefills:],
-                use_cuda_graph=self.use_cuda_graph)
+                use_cuda_graph=self.use_cuda_graph, decode_seq_order=self.decode_seq_order)
         return self._cached_decode_metadata
 
 
@@ -188,7 +192,8 @@ class Gfx950PagedAttentionImpl(AttentionImpl):
             output[n_pre:] = PagedAttention.forward_decode(
                 query[n_pre:], key_cache, value_cache, decode_meta.block_tables,
                 decode_meta.seq_lens_tensor, decode_meta.max_decode_seq_len, self.kv_cache_dtype,
-                self.num_kv_heads, self.scale, self._alibi(query.device), kv_scale)
+                self.num_kv_heads, self.scale, self._alibi(query.device), kv_scale,
+                seq_order=decode_meta.decode_seq_order)
         return output.view(num_tokens, hidden)
 
 

@@ -62,7 +62,8 @@ class PagedAttention:
                        alibi_slopes: Optional[torch.Tensor], kv_scale: float, tp_rank: int = 0,
                        blocksparse_local_blocks: int = 0, blocksparse_vert_stride: int = 0,
                        blocksparse_block_size: int = 64,
-                       blocksparse_head_sliding_step: int = 0) -> torch.Tensor:
+                       blocksparse_head_sliding_step: int = 0,
+                       seq_order: Optional[torch.Tensor] = None) -> torch.Tensor:
         output = torch.empty_like(query)
         block_size = value_cache.shape[3]
         num_seqs, num_heads, head_size = query.shape
@@ -71,7 +72,7 @@ class PagedAttention:
                                    block_tables, seq_lens, block_size, max_seq_len, alibi_slopes,
                                    kv_cache_dtype, kv_scale, tp_rank, blocksparse_local_blocks,
                                    blocksparse_vert_stride, blocksparse_block_size,
-                                   blocksparse_head_sliding_step)
+                                   blocksparse_head_sliding_step, seq_order)
         else:
             assert _PARTITION_SIZE % block_size == 0
             parts = (max_seq_len + _PARTITION_SIZE - 1) // _PARTITION_SIZE
@@ -84,7 +85,8 @@ class PagedAttention:
                                    value_cache, num_kv_heads, scale, block_tables, seq_lens,
                                    block_size, max_seq_len, alibi_slopes, kv_cache_dtype, kv_scale,
                                    tp_rank, blocksparse_local_blocks, blocksparse_vert_stride,
-                                   blocksparse_block_size, blocksparse_head_sliding_step)
+                                   blocksparse_block_size, blocksparse_head_sliding_step,
+                                   seq_order)
         return output
 
     @staticmethod

@@ -65,14 +65,14 @@ static int check_attn(const void* out, const void* query, const void* kc, const 
   return VLA_OK;
 }
 
-extern "C" int vla_paged_attention_v1(
+extern "C" int vla_paged_attention_v1_ordered(
     void* out, const void* query, const void* key_cache, const void* value_cache, int num_seqs,
     int num_heads, int num_kv_heads, int head_size, int block_size, float scale,
     const int* block_tables, const int* seq_lens, int max_num_blocks_per_seq, int max_seq_len,
     const float* alibi_slopes, int64_t q_stride, int64_t kv_block_stride, int64_t kv_head_stride,
     int dtype, int kv_dtype, float kv_scale, int tp_rank, int blocksparse_local_blocks,
     int blocksparse_vert_stride, int blocksparse_block_size, int blocksparse_head_sliding_step,
-    void* stream) {
+    const int* seq_order, void* stream) {
   (void)hipGetLastError();  // a stale error of some earlier HIP call must not fail this one
   (void)max_seq_len;
   if (blocksparse_vert_stride > 1 && blocksparse_block_size <= 0) return VLA_ERR_BLOCKSPARSE;
@@ -92,6 +92,7 @@ extern "C" int vla_paged_attention_v1(
   p.bs_vert_stride = blocksparse_vert_stride; p.bs_local_blocks = blocksparse_local_blocks;
   p.bs_block_size = blocksparse_block_size; p.bs_head_sliding_step = blocksparse_head_sliding_step;
   p.tp_rank = tp_rank;
+  p.seq_order = seq_order;
   hipStream_t s = (hipStream_t)stream;
   // the block-sparse variant (vert_stride > 1, ref attention_kernels.cu:821) runs on the generic
   // kernel only
@@ -101,14 +102,31 @@ extern "C" int vla_paged_attention_v1(
   return launch_paged_attention_generic(p, dtype, kv_dtype, s);
 }
 
-extern "C" int vla_paged_attention_v2(
+extern "C" int vla_paged_attention_v1(
+    void* out, const void* query, const void* key_cache, const void* value_cache, int num_seqs,
+    int num_heads, int num_kv_heads, int head_size, int block_size, float scale,
+    const int* block_tables, const int* seq_lens, int max_num_blocks_per_seq, int max_seq_len,
+    const float* alibi_slopes, int64_t q_stride, int64_t kv_block_stride, int64_t kv_head_stride,
+    int dtype, int kv_dtype, float kv_scale, int tp_rank, int blocksparse_local_blocks,
+    int blocksparse_vert_stride, int blocksparse_block_size, int blocksparse_head_sliding_step,
+    void* stream) {
+  return vla_paged_attention_v1_ordered(
+      out, query, key_cache, value_cache, num_seqs, num_heads, num_kv_heads, head_size, block_size,
+      scale, block_tables, seq_lens, max_num_blocks_per_seq, max_seq_len, alibi_slopes, q_stride,
+      kv_block_stride, kv_head_stride, dtype, kv_dtype, kv_scale, tp_rank, blocksparse_local_blocks,
+      blocksparse_vert_stride, blocksparse_block_size, blocksparse_head_sliding_step, nullptr,
+      stream);
+}
+
+extern "C" int vla_paged_attention_v2_ordered(
     void* out, float* exp_sums, float* max_logits, void* tmp_out, const void* query,
     const void* key_cache, const void* value_cache, int num_seqs, int num_heads,
     int num_kv_heads, int head_size, int block_size, float scale, const int* block_tables,
     const int* seq_lens, int max_num_blocks_per_seq, int max_seq_len, const float* alibi_slopes,
     int64_t q_stride, int64_t kv_block_stride, int64_t kv_head_stride, int dtype, int kv_dtype,
     float kv_scale, int tp_rank, int blocksparse_local_blocks, int blocksparse_vert_stride,
-    int blocksparse_block_size, int blocksparse_head_sliding_step, void* stream) {
+    int blocksparse_block_size, int blocksparse_head_sliding_step, const int* seq_order,
+    void* stream) {
   (void)hipGetLastError();  // a stale error of some earlier HIP call must not fail this one
   if (blocksparse_vert_stride > 1 && blocksparse_block_size <= 0) return VLA_ERR_BLOCKSPARSE;
   int rc = check_attn(out, query, key_cache, value_cache, num_seqs, num_heads, num_kv_heads,
@@ -130,6 +148,7 @@ extern "C" int vla_paged_attention_v2(
   p.bs_vert_stride = blocksparse_vert_stride; p.bs_local_blocks = blocksparse_local_blocks;
   p.bs_block_size = blocksparse_block_size; p.bs_head_sliding_step = blocksparse_head_sliding_step;
   p.tp_rank = tp_rank;
+  p.seq_order = seq_order;
   hipStream_t s = (hipStream_t)stream;
   const bool generic_only = g_attention_path == 1 || blocksparse_vert_stride > 1;
   rc = generic_only ? -1 : launch_paged_attention_mfma(p, dtype, kv_dtype, s);
@@ -137,4 +156,20 @@ extern "C" int vla_paged_attention_v2(
   if (rc != VLA_OK) return rc;
   return launch_paged_attention_v2_reduce(out, exp_sums, max_logits, tmp_out, seq_lens, num_seqs,
                                           num_heads, head_size, P, dtype, s);
+}
+
+extern "C" int vla_paged_attention_v2(
+    void* out, float* exp_sums, float* max_logits, void* tmp_out, const void* query,
+    const void* key_cache, const void* value_cache, int num_seqs, int num_heads,
+    int num_kv_heads, int head_size, int block_size, float scale, const int* block_tables,
+    const int* seq_lens, int max_num_blocks_per_seq, int max_seq_len, const float* alibi_slopes,
+    int64_t q_stride, int64_t kv_block_stride, int64_t kv_head_stride, int dtype, int kv_dtype,
+    float kv_scale, int tp_rank, int blocksparse_local_blocks, int blocksparse_vert_stride,
+    int blocksparse_block_size, int blocksparse_head_sliding_step, void* stream) {
+  return vla_paged_attention_v2_ordered(
+      out, exp_sums, max_logits, tmp_out, query, key_cache, value_cache, num_seqs, num_heads,
+      num_kv_heads, head_size, block_size, scale, block_tables, seq_lens, max_num_blocks_per_seq,
+      max_seq_len, alibi_slopes, q_stride, kv_block_stride, kv_head_stride, dtype, kv_dtype,
+      kv_scale, tp_rank, blocksparse_local_blocks, blocksparse_vert_stride, blocksparse_block_size,
+      blocksparse_head_sliding_step, nullptr, stream);
 }

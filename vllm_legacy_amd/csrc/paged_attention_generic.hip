@@ -94,7 +94,8 @@ __global__ __launch_bounds__(kThreads) void pa_generic_kernel(AttnParams p) {
   constexpr int VEC = C::kVec;
   constexpr int X = FP8 ? 16 : 16 / (int)sizeof(T);  // elements per 16-byte K chunk
 
-  const int head = blockIdx.x, seq = blockIdx.y, part = blockIdx.z;
+  const int head = blockIdx.x, seq = p.seq_order ? p.seq_order[blockIdx.y] : blockIdx.y;
+  const int part = blockIdx.z;
   const int tid = threadIdx.x;
   const int seq_len = p.seq_lens[seq];
   const int tok_begin = PARTITIONED ? part * kChunk : 0;

@@ -115,7 +115,7 @@ __global__ __launch_bounds__(kThreads, 2) void pa_mfma_kernel(AttnParams p, int 
   const int kv_head = blockIdx.x / groups_per_kv;
   const int head_base = kv_head * qpk + (blockIdx.x % groups_per_kv) * heads_per_wg;
   const int nheads = min(heads_per_wg, kv_head * qpk + qpk - head_base);
-  const int seq = blockIdx.y, part = blockIdx.z;
+  const int seq = p.seq_order ? p.seq_order[blockIdx.y] : blockIdx.y, part = blockIdx.z;
 
   const int seq_len = p.seq_lens[seq];
   const int tok_begin = PARTITIONED ? part * VLA_PARTITION_SIZE : 0;

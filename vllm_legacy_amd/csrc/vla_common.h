@@ -126,6 +126,7 @@ struct AttnParams {
   const void* v_cache;
   const int* block_tables;
   const int* seq_lens;
+  const int* seq_order;   // optional: grid row y works on sequence seq_order[y] (longest first)
   const float* alibi_slopes;
   int num_seqs, num_heads, num_kv_heads, head_size, block_size;
   int max_num_blocks_per_seq;
