@@ -271,12 +271,28 @@ def main():
         context_lens_tensor=None, block_tables=block_tables)
     next_ids = torch.empty((B, ), dtype=torch.int64, device=device)
 
+    hidden_buf = [None]
+
     @torch.inference_mode()
-    def step():
-        hidden = model(input_ids, positions, kv_caches, meta)
-        logits = model.compute_logits(hidden)
+    def forward_part():
+        hidden_buf[0] = model(input_ids, positions, kv_caches, meta)
+
+    @torch.inference_mode()
+    def logits_part():
+        logits = model.compute_logits(hidden_buf[0])
         if logits is not None:
             next_ids.copy_(torch.argmax(logits, dim=-1))
+
+    def step():
+        forward_part()
+        logits_part()
+
+    # One GPU: the whole step is captured.  Tensor parallel: the graph holds the layer stack (with
+    # its all-reduces), and the vocabulary-parallel logits with their gather to rank 0 run eagerly
+    # after each replay -- the split the reference uses (its graphs cover the model forward only,
+    # vllm/worker/model_runner.py:753-768), and a gather that cannot be captured then costs three
+    # launches instead of the whole graph.
+    captured = step if world == 1 else forward_part
 
     def barrier():
         if world > 1:
@@ -287,7 +303,10 @@ def main():
         stream)."""
         # ---- optional graph capture (decode is replayed from a graph in the reference too,
         # vllm/worker/model_runner.py:512-515)
-        use_graph = not args.no_graph and not rehearsal
+        # a rehearsal's Gloo collectives cannot be captured; with the peer-memory all-reduce in
+        # place the layer stack holds none, and the rehearsal covers the graph path as well
+        use_graph = not args.no_graph and (
+            not rehearsal or (ar_rec is not None and ar_rec["impl"] == "xgmi"))
         graph = None
         stream = torch.cuda.Stream(device=device)
         with torch.cuda.stream(stream):
@@ -300,7 +319,7 @@ def main():
                     # HIP calls of their own; they must not invalidate this thread's capture
                     mode = "thread_local" if world > 1 else "global"
                     with torch.cuda.graph(graph, stream=stream, capture_error_mode=mode):
-                        step()
+                        captured()
                 except Exception as e:  # e.g. a collective that cannot be captured
                     if rank == 0:
                         print(f"[bench] graph capture failed ({type(e).__name__}: "
@@ -314,7 +333,14 @@ def main():
                 pass
             stream = torch.cuda.Stream(device=device)
         with torch.cuda.stream(stream):
-            run = graph.replay if graph is not None else step
+            if graph is None:
+                run = step
+            elif world == 1:
+                run = graph.replay
+            else:
+                def run():
+                    graph.replay()
+                    logits_part()
             for _ in range(args.warmup):
                 run()
             torch.cuda.synchronize()
