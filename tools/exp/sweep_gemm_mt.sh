@@ -1,0 +1,9 @@
+#!/bin/bash
+# sweep row-tile height x K slices of the int4 GEMM at batch 256 over the small-N layer shapes
+cd "$(dirname "$0")/../.."
+for only in qkv o down; do
+  for cfg in "8,8,4" "8,4,4" "4,4,4" "4,8,4" "4,1,2" "4,2,2" "4,4,2" "4,8,2" "4,2,1" "4,4,1"; do
+    echo -n "$only nw,splits,mt=$cfg: "
+    VLA_Q4_TUNE="$cfg" timeout -k 10 60 python3 tools/gemm_bench.py --only $only --iters 20 2>/dev/null | grep -o '"us_median": [0-9.]*' || exit 1
+  done
+done

@@ -484,7 +484,7 @@ using namespace vla;
 //    8 slices 39.8 us) -- but never slices shorter than 8 K steps: below that the fixed cost of
 //    the slabs and their reduction exceeds what the shorter loop saves (K = 1024, N = 4096:
 //    1 slice 15.3 us, 4 slices 19.2 us).
-// VLA_Q4_TUNE="nw,splits" overrides both (kernel studies).
+// VLA_Q4_TUNE="nw,splits[,mt]" overrides them (kernel studies).
 struct Q4Shape { int nw, splits, mt; };
 
 static Q4Shape pick_shape(int m, int n, int k, int group) {
@@ -514,8 +514,10 @@ static Q4Shape pick_shape(int m, int n, int k, int group) {
   }
   if (want < 1) want = 1;
   if (const char* e = getenv("VLA_Q4_TUNE")) {
-    int a = 0, b = 0;
-    if (sscanf(e, "%d,%d", &a, &b) == 2 && (a == 4 || (a == 8 && s.mt == 4)) && b >= 1 && b <= 16) {
+    int a = 0, b = 0, c = 0;
+    const int got = sscanf(e, "%d,%d,%d", &a, &b, &c);
+    if (got == 3 && (c == 1 || c == 2 || c == 4)) s.mt = c;   // "nw,splits,mt"
+    if (got >= 2 && (a == 4 || (a == 8 && s.mt == 4)) && b >= 1 && b <= 16) {
       s.nw = a;
       want = b;
     }
