@@ -34,13 +34,17 @@ def main():
     ap.add_argument("--block", type=int, default=16)
     ap.add_argument("--head-size", type=int, default=128)
     ap.add_argument("--generic", action="store_true", help="force the coverage kernel")
+    ap.add_argument("--pool", type=int, default=0,
+                    help="the reference harness's set-up (benchmarks/kernels/benchmark_paged_attention.py"
+                         ":11, :59-63): a cache of this many blocks, block tables drawn from it with "
+                         "repeats, so the data stays cache resident (0: unique blocks, real HBM traffic)")
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
     dt = torch.float16 if a.dtype == "f16" else torch.bfloat16
     B, S, BS, D = a.batch, a.seq, a.block, a.head_size
     if a.generic:
         ops.set_attention_path(1)
-    nb = B * (S // BS)
+    nb = a.pool if a.pool else B * (S // BS)
     g = torch.Generator(device=dev).manual_seed(0)
     scale = D**-0.5
     fp8 = a.kv == "fp8"
@@ -62,7 +66,10 @@ def main():
         caches.append((kc, vc))
     q = torch.empty((B, a.hq, D), dtype=dt, device=dev).uniform_(-scale, scale, generator=g)
     out = torch.empty_like(q)
-    bt = torch.randperm(nb, generator=g, device=dev).to(torch.int32).view(B, S // BS).contiguous()
+    if a.pool:
+        bt = torch.randint(0, nb, (B, S // BS), generator=g, device=dev, dtype=torch.int32)
+    else:
+        bt = torch.randperm(nb, generator=g, device=dev).to(torch.int32).view(B, S // BS).contiguous()
     if a.ragged:
         sl = torch.randint(1, S + 1, (B, ), generator=g, device=dev, dtype=torch.int32)
         if a.sorted:
@@ -99,7 +106,7 @@ def main():
     tokens = int(sl.sum().item())
     algo = 2 * a.hkv * D * tokens * e_kv + 4 * B * (S // BS) + 2 * B * a.hq * D * 2 + 8 * B
     med = ts[len(ts) // 2]
-    print(json.dumps({"version": a.version, "kv": a.kv, "block": BS, "head_size": D, "generic": a.generic, "batch": B, "seq": S, "ragged": a.ragged,
+    print(json.dumps({"version": a.version, "kv": a.kv, "block": BS, "head_size": D, "generic": a.generic, "batch": B, "seq": S, "ragged": a.ragged, "pool": a.pool,
                       "ms_median": round(med, 4), "ms_min": round(ts[0], 4), "ms_mean": round(sum(ts) / len(ts), 4),
                       "algo_bytes": algo, "GBps_median": round(algo / med / 1e6, 1),
                       "frac_of_8TBps": round(algo / med / 1e6 / 8000, 4)}))
