@@ -61,3 +61,17 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
     with pytest.raises(ImportError, match="no fallback"):
         _lib.lib()
+
+
+def test_v1_v2_selection_rules():
+    """Host logic of forward_decode: the reference's rule when only query heads are known, the
+    workgroup-count rule of the gfx950 kernels (no 8192-token cap) when KV heads are given."""
+    from vllm_legacy_amd.attention.ops.paged_attn import PagedAttention as P
+    # reference rule (paged_attn.py:120-121)
+    assert P.use_v1(512, 1, 32) and P.use_v1(4096, 256, 32)
+    assert not P.use_v1(4096, 16, 32) and not P.use_v1(8193, 256, 32)
+    # gfx950 rule
+    assert P.use_v1(512, 1, 32, 8)                 # a single partition: nothing to split
+    assert not P.use_v1(4096, 8, 32, 8) and P.use_v1(4096, 16, 32, 8)
+    assert P.use_v1(16384, 32, 32, 8) and not P.use_v1(16384, 8, 32, 8)
+    assert not P.use_v1(4096, 64, 8, 1) and P.use_v1(4096, 128, 8, 1)   # one KV head per rank

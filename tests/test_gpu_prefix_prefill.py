@@ -180,3 +180,41 @@ def test_prefix_rejects_unsupported(ops):
     vc = torch.zeros((2, 2, 72, 16), dtype=torch.float16, device="cuda")
     with pytest.raises(RuntimeError, match="head size"):
         ops.prefix_prefill_attention(torch.empty_like(q72), q72, q72, q72, kc, vc, bt, qs, sl, ctx, 4, 1.0)
+
+
+def test_backend_passes_its_sliding_window_to_prefix_prefill(ops):
+    """The backend's constructor takes a sliding window as the reference's ROCm backend does
+    (rocm_flash_attn.py:215-216) and hands it to prefix-enabled prompt attention (:382): same
+    result as the op called with that window, different from the window-less result."""
+    from vllm_legacy_amd.attention.backends.gfx950_paged import (Gfx950PagedAttentionBackend,
+                                                                 Gfx950PagedAttentionMetadata)
+    dev = torch.device("cuda", 0)
+    hq, hkv, d, bs, window = 8, 2, 128, 16, 48
+    qlens, ctx = [40, 7, 130], [100, 64, 33]
+    q, k, v, kc, vc, table, _ = _case(21, qlens, ctx, hq, hkv, d, bs, O.DT_F16, False)
+    tq, tk, tv, tkc, tvc = [T.from_bits(a, O.DT_F16, "cuda") for a in (q, k, v, kc, vc)]
+    nb = tkc.shape[0]
+    cache = torch.stack([tkc.reshape(nb, -1), tvc.reshape(nb, -1)])
+    qs = torch.tensor(np.concatenate([[0], np.cumsum(qlens)]), dtype=torch.int32, device=dev)
+    sl = torch.tensor(np.add(ctx, qlens), dtype=torch.int32, device=dev)
+    cl = torch.tensor(ctx, dtype=torch.int32, device=dev)
+    bt = torch.from_numpy(table).cuda()
+    meta = Gfx950PagedAttentionMetadata(
+        num_prefills=len(qlens), num_prefill_tokens=sum(qlens), num_decode_tokens=0,
+        slot_mapping=torch.full((sum(qlens), ), -1, dtype=torch.int64, device=dev),
+        seq_lens=[int(a) for a in np.add(ctx, qlens)], seq_lens_tensor=sl, max_query_len=max(qlens),
+        max_prefill_seq_len=int(max(np.add(ctx, qlens))), max_decode_seq_len=0, query_start_loc=qs,
+        seq_start_loc=torch.tensor(np.concatenate([[0], np.cumsum(np.add(ctx, qlens))]), dtype=torch.int32,
+                                   device=dev),
+        use_cuda_graph=False, context_lens_tensor=cl, block_tables=bt)
+    outs = {}
+    for w in (None, window):
+        impl = Gfx950PagedAttentionBackend.get_impl_cls()(hq, d, d**-0.5, hkv, None, w, "auto", None)
+        outs[w] = impl.forward(tq.view(-1, hq * d), tk.view(-1, hkv * d), tv.view(-1, hkv * d), cache,
+                               meta, 1.0).view(-1, hq, d)
+    want = torch.empty_like(tq)
+    ops.prefix_prefill_attention(want, tq, tk, tv, tkc, tvc, bt, qs, sl, cl, max(qlens), d**-0.5, None,
+                                 window)
+    torch.cuda.synchronize()
+    assert torch.equal(outs[window], want)
+    assert not torch.allclose(outs[None].float(), want.float(), atol=1e-2)

@@ -106,8 +106,11 @@ class Gfx950PagedAttentionImpl(AttentionImpl):
                  blocksparse_params: Optional[Dict[str, Any]] = None) -> None:
         if blocksparse_params is not None:
             raise ValueError("the gfx950 paged-attention backend does not support blocksparse attention")
-        if sliding_window is not None:
-            raise ValueError("the gfx950 paged-attention backend does not support a sliding window")
+        # As in the reference's ROCm backend the window only reaches prefix-enabled prompt
+        # attention (rocm_flash_attn.py:215-216, :382); a prompt without a cached prefix attends
+        # causally to all of itself (:327-363) and decode relies on the caller handing in block
+        # tables and lengths already cut to the window (:385-399).
+        self.sliding_window = sliding_window
         self.num_heads = num_heads
         self.head_size = head_size
         self.scale = float(scale)
@@ -167,8 +170,8 @@ class Gfx950PagedAttentionImpl(AttentionImpl):
                     bt.to(torch.int32), prefill_meta.query_start_loc.to(torch.int32),
                     prefill_meta.seq_lens_tensor.to(torch.int32),
                     prefill_meta.context_lens_tensor.to(torch.int32),
-                    int(prefill_meta.max_query_len), self._alibi(query.device), None,
-                    self.kv_cache_dtype, kv_scale, self.scale)
+                    int(prefill_meta.max_query_len), self._alibi(query.device),
+                    self.sliding_window, self.kv_cache_dtype, kv_scale, self.scale)
             elif ops.prefill_attention_supported(query.dtype, self.head_size):
                 # HIP flash-style kernel over the packed prompt tokens; seq_start_loc is the
                 # cumulative prompt length table the reference's metadata carries

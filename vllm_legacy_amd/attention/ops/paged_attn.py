@@ -49,12 +49,22 @@ class PagedAttention:
                               kv_cache_dtype, kv_scale)
 
     @staticmethod
-    def use_v1(max_seq_len: int, num_seqs: int, num_heads: int) -> bool:
-        """The reference's heuristic (paged_attn.py:120-121), kept so that the same shapes take
-        the same entry point: one pass when there is a single partition or plenty of
-        (sequence, head) pairs, split-K + reduce otherwise or past 8192 tokens."""
+    def use_v1(max_seq_len: int, num_seqs: int, num_heads: int,
+               num_kv_heads: Optional[int] = None) -> bool:
+        """One pass (V1) or 512-token partitions + reduce (V2).
+
+        Without num_kv_heads: the reference's rule (paged_attn.py:120-121), which counts its
+        kernel's workgroups, one per (sequence, query head), and caps V1 at 8192 tokens because
+        that kernel keeps all logits in LDS.  With it: the rule for the gfx950 kernels, whose
+        workgroup serves a whole (sequence, KV head) group with an online softmax and has no
+        length cap -- V1 as soon as those groups alone give every other CU a workgroup.  Measured
+        with 8 KV heads and an fp8 cache: 4096 tokens, batch 8 V2 31 us / V1 47 us, batch 16
+        equal, batch 24 V1 41 / V2 46; 16384 tokens, batch 8 V2 60 / V1 96, batch 32 V1 185 / V2
+        211, batch 64 V1 369 / V2 411."""
         max_num_partitions = (max_seq_len + _PARTITION_SIZE - 1) // _PARTITION_SIZE
-        return max_seq_len <= 8192 and (max_num_partitions == 1 or num_seqs * num_heads > 512)
+        if num_kv_heads is None:
+            return max_seq_len <= 8192 and (max_num_partitions == 1 or num_seqs * num_heads > 512)
+        return max_num_partitions == 1 or num_seqs * num_kv_heads >= 128
 
     @staticmethod
     def forward_decode(query, key_cache, value_cache, block_tables, seq_lens, max_seq_len: int,
@@ -67,7 +77,7 @@ class PagedAttention:
         output = torch.empty_like(query)
         block_size = value_cache.shape[3]
         num_seqs, num_heads, head_size = query.shape
-        if PagedAttention.use_v1(max_seq_len, num_seqs, num_heads):
+        if PagedAttention.use_v1(max_seq_len, num_seqs, num_heads, num_kv_heads):
             ops.paged_attention_v1(output, query, key_cache, value_cache, num_kv_heads, scale,
                                    block_tables, seq_lens, block_size, max_seq_len, alibi_slopes,
                                    kv_cache_dtype, kv_scale, tp_rank, blocksparse_local_blocks,
