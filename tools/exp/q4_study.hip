@@ -664,7 +664,16 @@ __global__ __launch_bounds__(128 * WN) void q4_kernel5(
     step = min(step, nsteps - 1);
     const int k0 = k_begin + step * TK;
     const int grp = k0 / group_size;
-    if constexpr (OPT & 1) {
+    if constexpr (OPT & 16) {
+      // timing only: one 16-byte load per lane, as a [K/64][2][N][4]-word layout would allow
+      const u32x4 wv = *reinterpret_cast<const u32x4*>(qw + ((int64_t)(2 * (k0 / TK) + h) * n + ncl) * 4);
+      d.w[0] = wv[0]; d.w[1] = wv[1]; d.w[2] = wv[2]; d.w[3] = wv[3];
+      if constexpr (OPT & 32) { d.z = 0x88888888u; d.s = 0x21002100u; }
+      else {
+        d.z = zsrc[(int64_t)grp * (n >> 3)];
+        d.s = ssrc[(int64_t)grp * (n >> 1)];
+      }
+    } else if constexpr (OPT & 1) {
       const char* pb = reinterpret_cast<const char*>(qw + (int64_t)(k0 >> 3) * n);
 #pragma unroll
       for (int s = 0; s < 4; ++s)
@@ -1120,6 +1129,9 @@ int main(int argc, char** argv) {
 
   if (argc > 3 && !strcmp(argv[3], "base")) { run<0, 0>("baseline (pointer loads)", m, n, k, x, qw, qz, sc, out_ref, 5); return 0; }
   if (argc > 3 && !strcmp(argv[3], "v5")) { run5<0, 0>("V5", m, n, k, x, qw, qz, sc, out, 5); return 0; }
+  if (argc > 3 && !strcmp(argv[3], "v5wide")) { run5<0, 16>("V5 wide w", m, n, k, x, qw, qz, sc, out, 5); return 0; }
+  if (argc > 3 && !strcmp(argv[3], "v5widenozs")) { run5<0, 48>("V5 wide w, no z/s", m, n, k, x, qw, qz, sc, out, 5); return 0; }
+  if (argc > 3 && !strcmp(argv[3], "v5widenox")) { run5<ABL_NOX, 16>("V5 wide w, no x", m, n, k, x, qw, qz, sc, out, 5); return 0; }
   if (argc > 3 && !strcmp(argv[3], "v5nox")) { run5<ABL_NOX, 0>("V5 nox", m, n, k, x, qw, qz, sc, out, 5); return 0; }
   if (argc > 3 && !strcmp(argv[3], "v5now")) { run5<ABL_NOW, 0>("V5 now", m, n, k, x, qw, qz, sc, out, 5); return 0; }
   if (argc > 3 && !strcmp(argv[3], "v5noxw")) { run5<ABL_NOX | ABL_NOW, 0>("V5 noxw", m, n, k, x, qw, qz, sc, out, 5); return 0; }

@@ -215,7 +215,7 @@ struct Q4Groups {
   int64_t w_stride, z_stride, s_stride;   // elements between consecutive sets
 };
 
-template <int ZOFF, bool SPLIT, int NW, int MT, bool GROUPED = false>
+template <int ZOFF, bool SPLIT, int NW, int MT, bool GROUPED = false, bool G2 = false>
 __global__ __launch_bounds__(64 * NW) void q4_gemm_m32_kernel(
     const _Float16* __restrict__ x, const uint32_t* __restrict__ qw,
     const uint32_t* __restrict__ qz, const _Float16* __restrict__ scales, void* __restrict__ outp,
@@ -284,16 +284,25 @@ __global__ __launch_bounds__(64 * NW) void q4_gemm_m32_kernel(
   const uint32_t* ssrc = reinterpret_cast<const uint32_t*>(scales) + (ncl >> 1);
   const int zshift = 4 * (ncl & 7);
   const uint32_t ssel = (ncl & 1) ? 0x03020302u : 0x01000100u;
-  struct WStep { uint32_t w[4]; uint32_t z; uint32_t s; };  // s: the scale pair word
+  // The zero word and the scale pair word of a K step travel with its weight words, except when
+  // a group is exactly two K steps (G2, group size 128): then they are fetched once per group
+  // into a two-name ring of their own, two steps before the group's first step -- the two small
+  // loads per step cost as much issue time as the weight words themselves.
+  struct ZS { uint32_t z; uint32_t s; };
+  struct WStep { uint32_t w[4]; ZS zs; };
+  const int last_group = (k_end - 1) / group_size, group0 = k_begin / group_size;
+  auto load_zs = [&](int grp, ZS& d) {
+    grp = min(grp, last_group);
+    d.z = zsrc[(int64_t)grp * (n >> 3)];
+    d.s = ssrc[(int64_t)grp * (n >> 1)];
+  };
   auto load_w = [&](int step, WStep& d) {
     step = min(step, nsteps - 1);
     const int k0 = k_begin + step * TK;
     const uint32_t* p = wsrc + (int64_t)(k0 >> 3) * n;
 #pragma unroll
     for (int s = 0; s < 4; ++s) d.w[s] = p[(int64_t)(2 * s) * n];
-    const int grp = k0 / group_size;
-    d.z = zsrc[(int64_t)grp * (n >> 3)];
-    d.s = ssrc[(int64_t)grp * (n >> 1)];
+    if constexpr (!G2) load_zs(k0 / group_size, d.zs);
   };
 
   f32x16 acc[MT];
@@ -315,17 +324,24 @@ __global__ __launch_bounds__(64 * NW) void q4_gemm_m32_kernel(
   // `wnew`, compute step t from `wcur` and LDS buffer t & 1, then park x(t+1) (`xpark`, loaded
   // a step ago) in the other buffer.  Register sets rotate by NAME (the loop is unrolled by
   // four), so a register that a load is still writing is never copied.
-  auto k_step = [&](int t, const WStep& wcur, WStep& wnew, XSet& xnew, const XSet& xpark) {
+  // G2: zcur holds the constants of step t's group; on even steps znew receives those of the
+  // next group (the name the previous group has just released).
+  auto k_step = [&](int t, const WStep& wcur, WStep& wnew, XSet& xnew, const XSet& xpark,
+                    const ZS& zcur, ZS& znew) {
     const int buf = t & 1;
     load_x(t + 2, xnew);
     load_w(t + 3, wnew);
+    if constexpr (G2) {
+      if ((t & 1) == 0) load_zs(group0 + (t >> 1) + 1, znew);
+    }
     __builtin_amdgcn_sched_barrier(0);               // keep the loads at the top of the step
 
     // -(1024 + z) and -(64 + z) as fp16 bit patterns (ulp is 1 resp. 1/16 there, z <= 16)
-    const uint32_t z = ((wcur.z >> zshift) & 15u) + ZOFF;
+    const ZS& zs = G2 ? zcur : wcur.zs;
+    const uint32_t z = ((zs.z >> zshift) & 15u) + ZOFF;
     const f16x2 zc1 = as_h2((z * 0x00010001u) | 0xE400E400u);
     const f16x2 zc2 = as_h2((z * 0x00100010u) | 0xD400D400u);
-    const f16x2 sc2 = as_h2(__builtin_amdgcn_perm(wcur.s, wcur.s, ssel));
+    const f16x2 sc2 = as_h2(__builtin_amdgcn_perm(zs.s, zs.s, ssel));
 
     const unsigned char* xb = xs + buf * X2_TILE_BYTES;
     auto read_a = [&](int s, u32x4 (&af)[MT]) {
@@ -385,8 +401,10 @@ __global__ __launch_bounds__(64 * NW) void q4_gemm_m32_kernel(
 
   WStep w0, w1, w2, w3;
   XSet xa, xb_;
+  ZS za, zb;                       // G2: groups group0 + 2i in za, group0 + 2i + 1 in zb
   load_x(0, xa);
   load_x(1, xb_);
+  if constexpr (G2) load_zs(group0, za);
   load_w(0, w0);
   load_w(1, w1);
   load_w(2, w2);
@@ -395,14 +413,14 @@ __global__ __launch_bounds__(64 * NW) void q4_gemm_m32_kernel(
 
   int t = 0;
   for (; t + 4 <= nsteps; t += 4) {
-    k_step(t, w0, w3, xa, xb_);
-    k_step(t + 1, w1, w0, xb_, xa);
-    k_step(t + 2, w2, w1, xa, xb_);
-    k_step(t + 3, w3, w2, xb_, xa);
+    k_step(t, w0, w3, xa, xb_, za, zb);
+    k_step(t + 1, w1, w0, xb_, xa, za, zb);
+    k_step(t + 2, w2, w1, xa, xb_, zb, za);
+    k_step(t + 3, w3, w2, xb_, xa, zb, za);
   }
-  if (t < nsteps) k_step(t, w0, w3, xa, xb_);
-  if (t + 1 < nsteps) k_step(t + 1, w1, w0, xb_, xa);
-  if (t + 2 < nsteps) k_step(t + 2, w2, w1, xa, xb_);
+  if (t < nsteps) k_step(t, w0, w3, xa, xb_, za, zb);
+  if (t + 1 < nsteps) k_step(t + 1, w1, w0, xb_, xa, za, zb);
+  if (t + 2 < nsteps) k_step(t + 2, w2, w1, xa, xb_, zb, za);
 
   // ---- epilogue: lane (h, c) holds column ncol, rows (i & 3) + 8 (i >> 2) + 4 h of each 32-row tile
   if (!nok) return;
@@ -550,6 +568,7 @@ static int q4_gemm_run(const void* x, const int32_t* qweight, const int32_t* qze
   if (m == 0) return VLA_OK;
   hipStream_t s = (hipStream_t)stream;
   const bool m32 = group % TK == 0;                  // the 32x32 kernel wants whole K steps per group
+  static const bool g2_enabled = !(getenv("VLA_Q4_G2") && atoi(getenv("VLA_Q4_G2")) == 0);  // kernel studies
   Q4Shape shape = pick_shape(m, n, k, group);
   int splits = shape.splits;
   if (splits > 1 && (!workspace || workspace_bytes < (int64_t)splits * m * n * 4 ||
@@ -562,18 +581,29 @@ static int q4_gemm_run(const void* x, const int32_t* qweight, const int32_t* qze
 #define VLA_Q4_ARGS                                                                            \
   (const _Float16*)x, (const uint32_t*)qweight, (const uint32_t*)qzeros, (const _Float16*)scales, \
       dst, m, n, k, group, kps
+#define VLA_Q4_LAUNCH_G(Z, SP, G2)                                                             \
+  do {                                                                                         \
+    if (shape.mt == 1)                                                                         \
+      hipLaunchKernelGGL((q4_gemm_m32_kernel<Z, SP, 4, 1, false, G2>), grid, dim3(256), 0, s,  \
+                         VLA_Q4_ARGS);                                                         \
+    else if (shape.mt == 2)                                                                    \
+      hipLaunchKernelGGL((q4_gemm_m32_kernel<Z, SP, 4, 2, false, G2>), grid, dim3(256), 0, s,  \
+                         VLA_Q4_ARGS);                                                         \
+    else if (shape.nw == 8)                                                                    \
+      hipLaunchKernelGGL((q4_gemm_m32_kernel<Z, SP, 8, 4, false, G2>), grid, dim3(512), 0, s,  \
+                         VLA_Q4_ARGS);                                                         \
+    else                                                                                       \
+      hipLaunchKernelGGL((q4_gemm_m32_kernel<Z, SP, 4, 4, false, G2>), grid, dim3(256), 0, s,  \
+                         VLA_Q4_ARGS);                                                         \
+  } while (0)
 #define VLA_Q4_LAUNCH(Z, SP)                                                                   \
   do {                                                                                         \
     if (!m32)                                                                                  \
       hipLaunchKernelGGL((q4_gemm_fast_kernel<Z, SP>), grid, dim3(kThreadsG), 0, s, VLA_Q4_ARGS); \
-    else if (shape.mt == 1)                                                                    \
-      hipLaunchKernelGGL((q4_gemm_m32_kernel<Z, SP, 4, 1>), grid, dim3(256), 0, s, VLA_Q4_ARGS); \
-    else if (shape.mt == 2)                                                                    \
-      hipLaunchKernelGGL((q4_gemm_m32_kernel<Z, SP, 4, 2>), grid, dim3(256), 0, s, VLA_Q4_ARGS); \
-    else if (shape.nw == 8)                                                                    \
-      hipLaunchKernelGGL((q4_gemm_m32_kernel<Z, SP, 8, 4>), grid, dim3(512), 0, s, VLA_Q4_ARGS); \
+    else if (group == 2 * TK && g2_enabled)                                                    \
+      VLA_Q4_LAUNCH_G(Z, SP, true);                                                            \
     else                                                                                       \
-      hipLaunchKernelGGL((q4_gemm_m32_kernel<Z, SP, 4, 4>), grid, dim3(256), 0, s, VLA_Q4_ARGS); \
+      VLA_Q4_LAUNCH_G(Z, SP, false);                                                           \
   } while (0)
   if (zero_offset == 0) {
     if (splits > 1) VLA_Q4_LAUNCH(0, true); else VLA_Q4_LAUNCH(0, false);
@@ -581,6 +611,7 @@ static int q4_gemm_run(const void* x, const int32_t* qweight, const int32_t* qze
     if (splits > 1) VLA_Q4_LAUNCH(1, true); else VLA_Q4_LAUNCH(1, false);
   }
 #undef VLA_Q4_LAUNCH
+#undef VLA_Q4_LAUNCH_G
 #undef VLA_Q4_ARGS
   VLA_HIP_CHECK(hipGetLastError());
   if (splits > 1 && reduce) {
@@ -685,14 +716,18 @@ extern "C" int vla_q4_gemm_grouped(const void* x, const int32_t* qweight, const 
 #define VLA_Q4G_ARGS                                                                            \
   (const _Float16*)x, (const uint32_t*)qweight, (const uint32_t*)qzeros, (const _Float16*)scales, \
       dst, 0, n, k, group, kps, gp
-#define VLA_Q4G(Z, SP)                                                                          \
+#define VLA_Q4G_G(Z, SP, G2)                                                                    \
   do {                                                                                          \
     if (mt == 4)                                                                                \
-      hipLaunchKernelGGL((q4_gemm_m32_kernel<Z, SP, 4, 4, true>), grid, dim3(256), 0, s,        \
+      hipLaunchKernelGGL((q4_gemm_m32_kernel<Z, SP, 4, 4, true, G2>), grid, dim3(256), 0, s,    \
                          VLA_Q4G_ARGS);                                                         \
     else                                                                                        \
-      hipLaunchKernelGGL((q4_gemm_m32_kernel<Z, SP, 4, 2, true>), grid, dim3(256), 0, s,        \
+      hipLaunchKernelGGL((q4_gemm_m32_kernel<Z, SP, 4, 2, true, G2>), grid, dim3(256), 0, s,    \
                          VLA_Q4G_ARGS);                                                         \
+  } while (0)
+#define VLA_Q4G(Z, SP)                                                                          \
+  do {                                                                                          \
+    if (group == 2 * TK) VLA_Q4G_G(Z, SP, true); else VLA_Q4G_G(Z, SP, false);                  \
   } while (0)
   if (zero_offset == 0) {
     if (splits > 1) VLA_Q4G(0, true); else VLA_Q4G(0, false);
@@ -700,6 +735,7 @@ extern "C" int vla_q4_gemm_grouped(const void* x, const int32_t* qweight, const 
     if (splits > 1) VLA_Q4G(1, true); else VLA_Q4G(1, false);
   }
 #undef VLA_Q4G
+#undef VLA_Q4G_G
 #undef VLA_Q4G_ARGS
   VLA_HIP_CHECK(hipGetLastError());
   if (splits > 1) {
