@@ -9,7 +9,8 @@ import os
 import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libvla_gfx950.so")
+# VLA_LIB_PATH: another build of the same library (kernel studies: A/B in one process tree)
+LIB_PATH = os.environ.get("VLA_LIB_PATH") or os.path.join(HERE, "libvla_gfx950.so")
 CSRC = os.path.join(HERE, "csrc")
 
 F16, BF16, F32 = 0, 1, 2
