@@ -173,6 +173,17 @@ def select_all_reduce(device, world, rank, hidden, tokens, dtype):
                 want += parts[r].float()
             got = comm.all_reduce(x)
             ok = ok and torch.equal(got, want.to(dtype))
+        # the form the row-parallel linears use: unreduced split-K slabs as the input
+        if dtype in (torch.float16, torch.bfloat16):
+            from vllm_legacy_amd._custom_ops import SplitKSlabs
+            for ns in (2, 8):
+                ws = torch.empty(ns * tokens * hidden, dtype=torch.float32,
+                                 device=device).uniform_(-1, 1, generator=g)
+                slabs = SplitKSlabs(ws.view(torch.uint8), ns, tokens, hidden)
+                ok = ok and comm.takes_slabs(tokens, hidden, dtype)
+                if ok:
+                    got = comm.all_reduce_slabs(slabs, dtype)
+                    ok = torch.equal(got, comm.all_reduce(slabs.reduce(dtype).contiguous()))
         ok = ok and comm.error_count() == 0
 
         def timed(fn):

@@ -309,6 +309,14 @@ int vla_ar_destroy(void* ctx);
  * (custom_all_reduce.cuh:297-356 is the two-shot scheme this follows). */
 int vla_ar_all_reduce(void* ctx, void* out, const void* in, int64_t numel, int dtype,
                       void* stream);
+/* vla_ar_all_reduce whose input still is the unreduced output of an int4 GEMM that split K:
+ * num_slabs fp32 slabs of numel elements, slab_stride elements apart.  Each rank's slabs are
+ * summed in slab order and rounded to `dtype` (VLA_F16 / VLA_BF16) while they are published --
+ * the bits vla_q4_gemm_packed's own reduction produces -- so out equals vla_ar_all_reduce of the
+ * finished products, one launch earlier.  No counterpart in the reference (its GEMMs return
+ * finished matrices). */
+int vla_ar_all_reduce_slabs(void* ctx, void* out, const float* slabs, int num_slabs,
+                            int64_t slab_stride, int64_t numel, int dtype, void* stream);
 /* Synchronous.  A barrier wait that saw no peer within its poll limit gives up so that the kernel
  * terminates; *out counts those events on this rank (non-zero: results are invalid). */
 int vla_ar_error_count(void* ctx, int* out);

@@ -1,0 +1,89 @@
+"""One tensor-parallel rank of the Llama decode-stack test (started by test_gpu_fused.py; every
+rank on cuda:0, Gloo process groups).  Runs one decode step and saves rank 0's logits; with
+VLA_XGMI_ALLREDUCE=1 the row-parallel linears hand their unreduced split-K slabs to the
+peer-memory all-reduce, otherwise they reduce first and the all-reduce is staged through Gloo."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    rank, world, port, out_path = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    from vllm_legacy_amd import _custom_ops as ops
+    from vllm_legacy_amd.attention.backends.gfx950_paged import Gfx950PagedAttentionMetadata
+    from vllm_legacy_amd.distributed import communication_op as comm_op
+    from vllm_legacy_amd.distributed import parallel_state as ps
+    from vllm_legacy_amd.model.llama_decode import LlamaConfig, LlamaDecodeModel
+    ps.initialize_model_parallel(world, backend="gloo")
+    cfg = LlamaConfig(hidden_size=1024, intermediate_size=4096, num_hidden_layers=2,
+                      num_attention_heads=8, num_key_value_heads=2, head_dim=128, vocab_size=1024,
+                      max_position_embeddings=512)
+    model = LlamaDecodeModel(cfg, "awq", "fp8", device=dev, seed=3)
+    for layer in model.layers:
+        for lin in (layer.qkv_proj, layer.o_proj, layer.gate_up_proj, layer.down_proj):
+            lin.scales.data = (lin.scales.data.float() * 0.1).half()
+    # count how the all-reduce is fed
+    fed = {"slabs": 0, "tensors": 0}
+    inner = comm_op.tensor_model_parallel_all_reduce
+
+    def counting(x, *a, **k):
+        fed["slabs" if isinstance(x, ops.SplitKSlabs) else "tensors"] += 1
+        return inner(x, *a, **k)
+
+    import vllm_legacy_amd.model.llama_decode as ld
+    ld.tensor_model_parallel_all_reduce = counting
+
+    bs = 16
+    seq_lens = np.array([1, 5, 16, 17, 100, 200, 37, 64] * 8, dtype=np.int32)       # 64 sequences
+    B = len(seq_lens)
+    max_blocks = (int(seq_lens.max()) + bs - 1) // bs
+    num_blocks = B * max_blocks + 3
+    rng = np.random.default_rng(11)
+    block_tables = rng.permutation(num_blocks)[:B * max_blocks].reshape(B, max_blocks).astype(np.int32)
+    positions = (seq_lens - 1).astype(np.int64)
+    slot_mapping = np.array([block_tables[b, p // bs] * bs + p % bs for b, p in enumerate(positions)],
+                            dtype=np.int64)
+    input_ids = rng.integers(0, cfg.vocab_size, B).astype(np.int64)
+    shape = model.kv_cache_shape(num_blocks, bs)
+    g = torch.Generator(device=dev).manual_seed(5 + rank)
+    kv_caches = []
+    for _ in range(cfg.num_hidden_layers):
+        src = torch.empty(shape, dtype=torch.float16, device=dev).uniform_(-1, 1, generator=g)
+        c = torch.empty(shape, dtype=torch.uint8, device=dev)
+        ops.convert_fp8(c, src)
+        kv_caches.append(c)
+    meta = Gfx950PagedAttentionMetadata(
+        num_prefills=0, num_prefill_tokens=0, num_decode_tokens=B,
+        slot_mapping=torch.from_numpy(slot_mapping).to(dev), seq_lens=None,
+        seq_lens_tensor=torch.from_numpy(seq_lens).to(dev), max_query_len=None,
+        max_prefill_seq_len=0, max_decode_seq_len=int(seq_lens.max()), query_start_loc=None,
+        seq_start_loc=None, use_cuda_graph=False, context_lens_tensor=None,
+        block_tables=torch.from_numpy(block_tables).to(dev))
+    with torch.inference_mode():
+        hidden = model(torch.from_numpy(input_ids).to(dev), torch.from_numpy(positions).to(dev),
+                       kv_caches, meta)
+        logits = model.compute_logits(hidden)
+    torch.cuda.synchronize()
+    xg = ps.get_tp_xgmi_all_reduce(dev)
+    if os.environ.get("VLA_XGMI_ALLREDUCE") == "1":
+        assert xg is not None and not xg.disabled and xg.error_count() == 0
+        assert fed["slabs"] > 0, fed          # the split-K layers went in unreduced
+    else:
+        assert xg is None and fed["slabs"] == 0, fed
+    if rank == 0:
+        np.savez(out_path, logits=logits.float().cpu().numpy(), slabs=fed["slabs"], tensors=fed["tensors"])
+    dist.barrier()
+    ps.destroy_model_parallel()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -3,6 +3,7 @@ add + RMSNorm fed by unreduced split-K slabs.  Expectations come from the oracle
 the separate reference kernels run back to back (rotary_embedding then reshape_and_cache;
 sum-and-round then fused_add_rms_norm); integer/byte results (cache contents, rotated q/k, the
 residual sum) are compared bit for bit, the normalised output within one unit of the last place."""
+import os
 import numpy as np
 import pytest
 import torch
@@ -121,3 +122,41 @@ def test_partial_gemm_slabs_reduce_to_the_full_result(ops, k, n):
     got = part.reduce() if isinstance(part, ops.SplitKSlabs) else part
     torch.cuda.synchronize()
     assert torch.equal(got, full)
+
+
+def _run_llama_tp(tmp_path, world, xgmi):
+    import socket
+    import subprocess
+    import sys
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / f"llama_tp_{int(xgmi)}.npz")
+    here = os.path.dirname(os.path.abspath(__file__))
+    procs = [subprocess.Popen([sys.executable, "-u", os.path.join(here, "llama_tp_worker.py"), str(r), str(world),
+                               str(port), out], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                              env=dict(os.environ, VLA_XGMI_ALLREDUCE="1" if xgmi else "0",
+                                       HSA_ENABLE_IPC_MODE_LEGACY="0"))
+             for r in range(world)]
+    try:
+        res = [p.communicate(timeout=150) + (p.returncode, ) for p in procs]
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    for so, se, rc in res:
+        assert rc == 0, se[-3000:]
+    return np.load(out)
+
+
+def test_tensor_parallel_step_with_slabs_into_the_peer_memory_all_reduce(tmp_path):
+    """Two ranks on one GPU, one decode step of a two-layer stack.  With the peer-memory
+    all-reduce the row-parallel linears leave their split-K slabs unreduced and the all-reduce
+    sums them while publishing; without it they reduce first and the sum is staged through Gloo.
+    Each rank's contribution is rounded to fp16 once either way and a two-rank sum has a single
+    rounding, so the logits agree bit for bit."""
+    a = _run_llama_tp(tmp_path, 2, xgmi=True)
+    b = _run_llama_tp(tmp_path, 2, xgmi=False)
+    assert int(a["slabs"]) > 0 and int(b["slabs"]) == 0
+    assert np.isfinite(a["logits"]).all() and float(np.abs(a["logits"]).max()) > 0.1
+    assert np.array_equal(a["logits"], b["logits"])

@@ -47,6 +47,31 @@ def main():
                 got = out.cpu()
                 assert torch.equal(got.view(torch.uint8), want.view(torch.uint8)), (
                     dtype, numel, inplace, got[:8].tolist(), want[:8].tolist())
+    # ---- unreduced split-K slabs as the input: each rank's slabs are summed (fp32, slab order)
+    # and rounded once, then the ranks' values are summed as above
+    from vllm_legacy_amd._custom_ops import SplitKSlabs
+    for dtype in (torch.float16, torch.bfloat16):
+        for m, n, ns in ((3, 64, 2), (256, 4096, 8), (17, 1000, 5)):
+            call += 1
+            g = torch.Generator().manual_seed(77 * call)
+            per_rank = [torch.empty((ns, m, n), dtype=torch.float32).uniform_(-1, 1, generator=g)
+                        for _ in range(world)]
+            acc = torch.zeros((m, n), dtype=torch.float32)
+            for r in range(world):
+                part = per_rank[r][0].clone()
+                for p in range(1, ns):
+                    part += per_rank[r][p]
+                acc += part.to(dtype).float()
+            want = acc.to(dtype)
+            ws = per_rank[rank].to(dev).view(-1).view(torch.uint8)
+            slabs = SplitKSlabs(ws, ns, m, n)
+            assert comm.takes_slabs(m, n, dtype)
+            got = comm.all_reduce_slabs(slabs, dtype).cpu()
+            assert torch.equal(got.view(torch.uint8), want.view(torch.uint8)), ("slabs", dtype, m, n, ns)
+            # and the same bits as reducing first and all-reducing the finished tensor
+            two = comm.all_reduce(slabs.reduce(dtype).contiguous()).cpu()
+            assert torch.equal(two.view(torch.uint8), got.view(torch.uint8))
+    assert not comm.takes_slabs(1024, 4096, torch.float16)        # 8 MiB > this communicator's 4
     # messages the communicator declines
     assert comm.custom_all_reduce(torch.zeros(7, dtype=torch.float16, device=dev)) is None
     assert comm.custom_all_reduce(torch.zeros((5 << 20), dtype=torch.float16, device=dev)) is None

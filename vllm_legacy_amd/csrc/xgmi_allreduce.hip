@@ -137,11 +137,34 @@ __device__ __forceinline__ void ar_copy(u32x4* dst, const u32x4* src, int64_t fi
   for (; i < len; i += stride) dst[i] = src[i];
 }
 
-// nvec: 16-byte units of the message; per: units per slice (the last slice may be short or empty)
+// dst[i] = S(sum over slabs of slab[p][i]) for 16-byte units i = first, first + stride, ... < len
+// of dst (8 elements each): fp32 sums in slab order rounded once, the arithmetic of the int4
+// GEMM's own split-K reduction
 template <class S>
+__device__ __forceinline__ void ar_copy_slabs(u32x4* dst, const float* slabs, int num_slabs,
+                                              int64_t slab_stride, int64_t first, int64_t len,
+                                              int64_t stride) {
+  for (int64_t i = first; i < len; i += stride) {
+    const f32x4* src = reinterpret_cast<const f32x4*>(slabs) + 2 * i;
+    f32x4 lo = src[0], hi = src[1];
+    for (int p = 1; p < num_slabs; ++p) {
+      const f32x4* q = reinterpret_cast<const f32x4*>(slabs + (int64_t)p * slab_stride) + 2 * i;
+      lo += q[0];
+      hi += q[1];
+    }
+    const float acc[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    dst[i] = ar_pack<S>(acc);
+  }
+}
+
+// nvec: 16-byte units of the message; per: units per slice (the last slice may be short or empty).
+// SLABS: the input is num_slabs fp32 partial products [num_slabs][numel] (an int4 GEMM whose K
+// range was split) that are summed and rounded to S while they are published.
+template <class S, bool SLABS = false>
 __global__ __launch_bounds__(AR_THREADS) void xgmi_two_shot_kernel(ArParams P, u32x4* out,
                                                                    const u32x4* in, int64_t nvec,
-                                                                   int64_t per) {
+                                                                   int64_t per, int num_slabs = 0,
+                                                                   int64_t slab_stride = 0) {
   unsigned char* self = P.region[P.rank];
   uint32_t* seq_slot = reinterpret_cast<uint32_t*>(self + AR_SEQ_OFF) + blockIdx.x;
   const uint32_t seq = __hip_atomic_load(seq_slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -153,7 +176,11 @@ __global__ __launch_bounds__(AR_THREADS) void xgmi_two_shot_kernel(ArParams P, u
   u32x4* mine = reinterpret_cast<u32x4*>(self + half);
   for (int s = 0; s < P.world; ++s) {
     const int64_t base = s * per, len = min(per, nvec - base);
-    ar_copy(mine + base, in + base, first, len, stride);
+    if constexpr (SLABS)
+      ar_copy_slabs<S>(mine + base, reinterpret_cast<const float*>(in) + 8 * base, num_slabs,
+                       slab_stride, first, len, stride);
+    else
+      ar_copy(mine + base, in + base, first, len, stride);
   }
   ar_barrier(P, seq + 1);
 
@@ -296,14 +323,39 @@ extern "C" int vla_ar_all_reduce(void* ctx, void* out, const void* in, int64_t n
   hipStream_t s = (hipStream_t)stream;
   // an empty message still runs the barriers: every rank must pass the same sequence
   if (dtype == VLA_F16)
-    hipLaunchKernelGGL(xgmi_two_shot_kernel<F16>, grid, block, 0, s, c->p, (u32x4*)out,
-                       (const u32x4*)in, nvec, per);
+    hipLaunchKernelGGL((xgmi_two_shot_kernel<F16>), grid, block, 0, s, c->p, (u32x4*)out,
+                       (const u32x4*)in, nvec, per, 0, (int64_t)0);
   else if (dtype == VLA_BF16)
-    hipLaunchKernelGGL(xgmi_two_shot_kernel<BF16>, grid, block, 0, s, c->p, (u32x4*)out,
-                       (const u32x4*)in, nvec, per);
+    hipLaunchKernelGGL((xgmi_two_shot_kernel<BF16>), grid, block, 0, s, c->p, (u32x4*)out,
+                       (const u32x4*)in, nvec, per, 0, (int64_t)0);
   else
-    hipLaunchKernelGGL(xgmi_two_shot_kernel<F32>, grid, block, 0, s, c->p, (u32x4*)out,
-                       (const u32x4*)in, nvec, per);
+    hipLaunchKernelGGL((xgmi_two_shot_kernel<F32>), grid, block, 0, s, c->p, (u32x4*)out,
+                       (const u32x4*)in, nvec, per, 0, (int64_t)0);
+  VLA_HIP_CHECK(hipGetLastError());
+  return VLA_OK;
+}
+
+extern "C" int vla_ar_all_reduce_slabs(void* ctx, void* out, const float* slabs, int num_slabs,
+                                       int64_t slab_stride, int64_t numel, int dtype,
+                                       void* stream) {
+  (void)hipGetLastError();
+  ArContext* c = static_cast<ArContext*>(ctx);
+  if (!c || !out || !slabs || numel < 0 || num_slabs < 1 || slab_stride < numel) return VLA_ERR_ARG;
+  if (dtype != VLA_F16 && dtype != VLA_BF16) return VLA_ERR_DTYPE;
+  const int64_t bytes = numel * 2;
+  if (bytes % 16 || bytes > c->p.max_bytes || ((uintptr_t)out % 16) || ((uintptr_t)slabs % 16) ||
+      slab_stride % 4)
+    return VLA_ERR_ARG;
+  const int64_t nvec = bytes / 16;
+  const int64_t per = (nvec + c->p.world - 1) / c->p.world;
+  dim3 grid(c->num_blocks), block(AR_THREADS);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == VLA_F16)
+    hipLaunchKernelGGL((xgmi_two_shot_kernel<F16, true>), grid, block, 0, s, c->p, (u32x4*)out,
+                       (const u32x4*)slabs, nvec, per, num_slabs, slab_stride);
+  else
+    hipLaunchKernelGGL((xgmi_two_shot_kernel<BF16, true>), grid, block, 0, s, c->p, (u32x4*)out,
+                       (const u32x4*)slabs, nvec, per, num_slabs, slab_stride);
   VLA_HIP_CHECK(hipGetLastError());
   return VLA_OK;
 }

@@ -21,10 +21,27 @@ from .parallel_state import (get_tp_xgmi_all_reduce,
                              get_tensor_model_parallel_world_size)
 
 
-def tensor_model_parallel_all_reduce(input_: torch.Tensor) -> torch.Tensor:
-    """SUM over the TP group, in place; returns its argument."""
-    if get_tensor_model_parallel_world_size() == 1 or not isinstance(input_, torch.Tensor):
+def tensor_model_parallel_takes_slabs(m: int, n: int, dtype: torch.dtype, device) -> bool:
+    """Whether tensor_model_parallel_all_reduce can be handed the unreduced split-K slabs
+    (ops.SplitKSlabs) of an [m, n] product: a single rank passes them through to a fused consumer;
+    several ranks need the peer-memory all-reduce, which sums them while it publishes them."""
+    if get_tensor_model_parallel_world_size() == 1:
+        return True
+    xgmi = get_tp_xgmi_all_reduce(device)
+    return xgmi is not None and xgmi.takes_slabs(m, n, dtype)
+
+
+def tensor_model_parallel_all_reduce(input_, dtype: torch.dtype = torch.float16) -> torch.Tensor:
+    """SUM over the TP group, in place; returns its argument.  Unreduced split-K slabs (see
+    tensor_model_parallel_takes_slabs) come back as the finished [m, n] tensor of `dtype` when
+    there is more than one rank."""
+    if get_tensor_model_parallel_world_size() == 1:
         return input_                     # single rank (possibly unreduced split-K slabs)
+    if not isinstance(input_, torch.Tensor):
+        xgmi = get_tp_xgmi_all_reduce(input_.workspace.device)
+        if xgmi is not None and xgmi.takes_slabs(input_.m, input_.n, dtype):
+            return xgmi.all_reduce_slabs(input_, dtype)
+        input_ = input_.reduce(dtype)     # a caller that did not ask first: sum here, then as usual
     group = get_tensor_model_parallel_group()
     if input_.is_cuda:
         # opt-in: direct loads/stores over xGMI peer memory instead of an RCCL call

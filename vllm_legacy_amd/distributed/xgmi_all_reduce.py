@@ -120,6 +120,26 @@ class XgmiAllReduce:
                 torch.cuda.current_stream(inp.device).cuda_stream), "ar_all_reduce")
         return out
 
+    def takes_slabs(self, m: int, n: int, dtype: torch.dtype) -> bool:
+        """Whether all_reduce_slabs can take the unreduced [m, n] product of an int4 GEMM."""
+        nbytes = m * n * 2
+        return (not self.disabled and dtype in (torch.float16, torch.bfloat16)
+                and nbytes % 16 == 0 and nbytes <= self.max_size)
+
+    def all_reduce_slabs(self, slabs, dtype: torch.dtype = torch.float16) -> torch.Tensor:
+        """slabs: ops.SplitKSlabs of this rank's partial product.  Same bits as all_reduce of
+        slabs.reduce(dtype), without the reduction launch."""
+        assert self.takes_slabs(slabs.m, slabs.n, dtype)
+        ws = slabs.workspace
+        out = torch.empty((slabs.m, slabs.n), dtype=dtype, device=ws.device)
+        numel = slabs.m * slabs.n
+        code = {torch.float16: _lib.F16, torch.bfloat16: _lib.BF16}[dtype]
+        with torch.cuda.device(ws.device):
+            _lib.check(_lib.lib().vla_ar_all_reduce_slabs(
+                self._ctx, out.data_ptr(), ws.data_ptr(), slabs.num_slabs, numel, numel, code,
+                torch.cuda.current_stream(ws.device).cuda_stream), "ar_all_reduce_slabs")
+        return out
+
     def custom_all_reduce(self, input: torch.Tensor) -> Optional[torch.Tensor]:
         if self.disabled or not self.should_custom_ar(input):
             return None

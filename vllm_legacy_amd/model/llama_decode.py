@@ -20,7 +20,8 @@ from vllm_legacy_amd import _custom_ops as ops
 from vllm_legacy_amd.attention.layer import Attention
 from vllm_legacy_amd.attention.ops.paged_attn import PagedAttention
 from vllm_legacy_amd.distributed.communication_op import (tensor_model_parallel_all_reduce,
-                                                          tensor_model_parallel_gather)
+                                                          tensor_model_parallel_gather,
+                                                          tensor_model_parallel_takes_slabs)
 from vllm_legacy_amd.distributed.parallel_state import (get_tensor_model_parallel_rank,
                                                         get_tensor_model_parallel_world_size)
 from vllm_legacy_amd.layers import RMSNorm, RotaryEmbedding, SiluAndMul
@@ -148,11 +149,16 @@ class LlamaDecodeLayer(nn.Module):
         else:
             rotary_emb(positions, q, k)     # in place on the strided views of qkv
             attn_out = self.attn(q, k, v, kv_cache, attn_metadata)
-        fuse = self.tp == 1                 # with TP the partial sums must be all-reduced first
-        hidden = tensor_model_parallel_all_reduce(self.o_proj(attn_out, defer_reduce=fuse))
+        # Split-K slabs of the row-parallel linears are left unreduced when the next step can sum
+        # them itself: the add + RMSNorm kernel on a single rank, the peer-memory all-reduce with
+        # several (RCCL needs the finished tensor).
+        fuse = tensor_model_parallel_takes_slabs(hidden.shape[0], self.cfg.hidden_size, hidden.dtype,
+                                                 hidden.device)
+        hidden = tensor_model_parallel_all_reduce(self.o_proj(attn_out, defer_reduce=fuse),
+                                                  hidden.dtype)
         hidden, residual = self.post_attention_layernorm(hidden, residual)
         hidden = tensor_model_parallel_all_reduce(
-            self.down_proj(self.act_fn(self.gate_up_proj(hidden)), defer_reduce=fuse))
+            self.down_proj(self.act_fn(self.gate_up_proj(hidden)), defer_reduce=fuse), hidden.dtype)
         return hidden, residual
 
 
