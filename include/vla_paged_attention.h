@@ -317,6 +317,17 @@ int vla_ar_all_reduce(void* ctx, void* out, const void* in, int64_t numel, int d
  * finished matrices). */
 int vla_ar_all_reduce_slabs(void* ctx, void* out, const float* slabs, int num_slabs,
                             int64_t slab_stride, int64_t numel, int dtype, void* stream);
+/* The all-reduce of a row-parallel linear's output followed by what the layer does next with it,
+ * residual = sum + residual; out = RMSNorm(residual) * weight (fused_add_rms_norm, csrc/ops.h:55-59,
+ * as called from vllm/model_executor/models/llama.py:213-224), in one launch.
+ *   in: [rows, hidden] of `dtype`, or with num_slabs > 0 that many fp32 slabs, slab_stride
+ *   elements apart (see vla_ar_all_reduce_slabs); residual [rows, hidden] in/out; weight [hidden];
+ *   out [rows, hidden].  hidden / 8 must be a multiple of the world size and at most 1024.
+ * residual receives the bits of the separate calls; out may differ from them in the last place
+ * (the sum of squares is accumulated in another order).  No counterpart in the reference. */
+int vla_ar_all_reduce_add_rms_norm(void* ctx, void* out, const void* in, int num_slabs,
+                                   int64_t slab_stride, void* residual, const void* weight,
+                                   float epsilon, int rows, int hidden, int dtype, void* stream);
 /* Synchronous.  A barrier wait that saw no peer within its poll limit gives up so that the kernel
  * terminates; *out counts those events on this rank (non-zero: results are invalid). */
 int vla_ar_error_count(void* ctx, int* out);

@@ -72,6 +72,37 @@ def main():
             two = comm.all_reduce(slabs.reduce(dtype).contiguous()).cpu()
             assert torch.equal(two.view(torch.uint8), got.view(torch.uint8))
     assert not comm.takes_slabs(1024, 4096, torch.float16)        # 8 MiB > this communicator's 4
+    # ---- all-reduce + residual add + RMSNorm in one launch, tensor and slab inputs: the residual
+    # gets the bits of the separate calls, the normalised rows agree to the last place
+    from vllm_legacy_amd import _custom_ops as ops
+    for dtype in (torch.float16, torch.bfloat16):
+        for m, n, ns in ((1, 64 * world, 0), (37, 1024 * world, 3), (256, 4096, 0), (256, 4096, 8),
+                         (5, 8192, 2)):
+            if (n // 8) % world:
+                assert not comm.takes_add_rms_norm(m, n, dtype)
+                continue
+            call += 1
+            g = torch.Generator().manual_seed(91 * call)
+            res0 = torch.empty((m, n), dtype=torch.float32).uniform_(-1, 1, generator=g).to(dtype)
+            weight = torch.empty(n, dtype=torch.float32).uniform_(0.5, 1.5, generator=g).to(dtype)
+            per_rank = [torch.empty((max(ns, 1), m, n), dtype=torch.float32).uniform_(-1, 1, generator=g)
+                        for _ in range(world)]
+            if ns:
+                x = SplitKSlabs(per_rank[rank].to(dev).view(-1).view(torch.uint8), ns, m, n)
+                plain = comm.all_reduce_slabs(x, dtype)
+            else:
+                x = per_rank[rank][0].to(dtype).to(dev)
+                plain = comm.all_reduce(x)
+            res_a, res_b = res0.to(dev), res0.to(dev)
+            ops.fused_add_rms_norm(plain, res_a, weight.to(dev), 1e-5)      # plain <- normed
+            got = comm.all_reduce_add_rms_norm(x, res_b, weight.to(dev), 1e-5)
+            torch.cuda.synchronize()
+            assert torch.equal(res_a.view(torch.int16), res_b.view(torch.int16)), ("residual", dtype, m, n, ns)
+            # a last-place step in x * inv, multiplied by the weight and rounded again: two units
+            ulp = 2.0**-10 if dtype == torch.float16 else 2.0**-7
+            torch.testing.assert_close(got.float(), plain.float(), rtol=2 * ulp, atol=1e-6)
+            frac = (got != plain).float().mean().item()
+            assert frac < 0.02, ("too many last-place differences", frac)
     # messages the communicator declines
     assert comm.custom_all_reduce(torch.zeros(7, dtype=torch.float16, device=dev)) is None
     assert comm.custom_all_reduce(torch.zeros((5 << 20), dtype=torch.float16, device=dev)) is None

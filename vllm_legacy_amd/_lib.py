@@ -31,7 +31,7 @@ EXPORTS = [
     "vla_fused_add_rms_norm", "vla_rotary_embedding", "vla_silu_and_mul",
     "vla_prefill_attention", "vla_prefix_prefill_attention", "vla_ar_region_bytes", "vla_ar_alloc_region",
     "vla_ar_free_region", "vla_ar_export", "vla_ar_import", "vla_ar_unimport", "vla_ar_create", "vla_ar_destroy",
-    "vla_ar_all_reduce", "vla_ar_all_reduce_slabs", "vla_ar_error_count", "vla_q4_gemm_grouped", "vla_q4_gemm_grouped_workspace_bytes",
+    "vla_ar_all_reduce", "vla_ar_all_reduce_slabs", "vla_ar_all_reduce_add_rms_norm", "vla_ar_error_count", "vla_q4_gemm_grouped", "vla_q4_gemm_grouped_workspace_bytes",
     "vla_q4_gemm_packed_partial", "vla_rotary_reshape_and_cache", "vla_fused_add_rms_norm_splitk",
 ]
 
@@ -103,6 +103,7 @@ def lib():
         L.vla_ar_destroy.argtypes = [p]
         L.vla_ar_all_reduce.argtypes = [p, p, p, i64, i, p]
         L.vla_ar_all_reduce_slabs.argtypes = [p, p, p, i, i64, i64, i, p]
+        L.vla_ar_all_reduce_add_rms_norm.argtypes = [p, p, p, i, i64, p, p, f, i, i, i, p]
         L.vla_ar_error_count.argtypes = [p, p]
         L.vla_q4_gemm_packed_partial.argtypes = [p, p, p, p, p, i, i, i, i, i, p, i64, p, p]
         L.vla_rotary_reshape_and_cache.argtypes = [p, p, p, p, p, p, p, p, i, i, i, i, i, i64, i64,

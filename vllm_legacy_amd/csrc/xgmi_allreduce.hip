@@ -211,6 +211,138 @@ __global__ __launch_bounds__(AR_THREADS) void xgmi_two_shot_kernel(ArParams P, u
   if (threadIdx.x == 0) __hip_atomic_store(seq_slot, seq + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+template <class S>
+__device__ __forceinline__ void ar_unpack(const u32x4 w, float (&f)[8]) {
+  using T = typename S::T;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    f[2 * i] = S::to_f32(__builtin_bit_cast(T, (uint16_t)(w[i] & 0xffffu)));
+    f[2 * i + 1] = S::to_f32(__builtin_bit_cast(T, (uint16_t)(w[i] >> 16)));
+  }
+}
+
+template <class S>
+__device__ __forceinline__ float ar_rnd(float v) { return S::to_f32(S::from_f32(v)); }
+
+// Sum of one value per thread over the workgroup (AR_THREADS threads).
+__device__ __forceinline__ float ar_block_sum(float v, float* red) {
+  v = wave_sum(v);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float r = 0.f;
+#pragma unroll
+  for (int i = 0; i < AR_THREADS / 64; ++i) r += red[i];
+  __syncthreads();
+  return r;
+}
+
+// The all-reduce followed by the layer's next step, residual = sum + residual and
+// out = RMSNorm(residual) * weight (csrc/layernorm_kernels.cu:52-91, the pair
+// vllm/model_executor/models/llama.py:213-224 runs after each row-parallel linear), in one launch.
+// The element-to-block map is by rows instead of the strided walk above: block b owns rows
+// b, b + G, ... in all three steps (so the pairing of block b with block b of the peers still
+// covers every dependency), rank r reduces the r-th column range of each row, and in step 3 a
+// block holds whole rows of the sum, which is what the normalisation needs.
+// rv: 16-byte units per row (hidden / 8), a multiple of the world size, at most 2 * AR_THREADS.
+constexpr int AR_ROW_CHUNK = 4;   // rows whose loads are in flight together in step 3
+template <class S, bool SLABS>
+__global__ __launch_bounds__(AR_THREADS) void xgmi_two_shot_norm_kernel(
+    ArParams P, u32x4* out, const u32x4* in, u32x4* residual, const u32x4* weight, float eps,
+    int rows, int rv, int num_slabs, int64_t slab_stride) {
+  __shared__ float red[AR_THREADS / 64];
+  unsigned char* self = P.region[P.rank];
+  uint32_t* seq_slot = reinterpret_cast<uint32_t*>(self + AR_SEQ_OFF) + blockIdx.x;
+  const uint32_t seq = __hip_atomic_load(seq_slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const int64_t half = AR_DATA_OFF + (int64_t)((seq >> 1) & 1u) * P.max_bytes;
+  const int G = gridDim.x, b = blockIdx.x, t = threadIdx.x;
+  u32x4* mine = reinterpret_cast<u32x4*>(self + half);
+
+  // 1. publish this block's rows
+  for (int row = b; row < rows; row += G) {
+    const int64_t r0 = (int64_t)row * rv;
+    if constexpr (SLABS)
+      ar_copy_slabs<S>(mine + r0, reinterpret_cast<const float*>(in) + 8 * r0, num_slabs,
+                       slab_stride, t, rv, AR_THREADS);
+    else
+      for (int v = t; v < rv; v += AR_THREADS) mine[r0 + v] = in[r0 + v];
+  }
+  ar_barrier(P, seq + 1);
+
+  // 2. this rank's column range of this block's rows, summed over the ranks in place
+  const int cw = rv / P.world, c0 = P.rank * cw;
+  {
+    const int my_rows = b < rows ? (rows - b + G - 1) / G : 0;
+    for (int item = t; item < my_rows * cw; item += AR_THREADS) {
+      const int64_t idx = (int64_t)(b + (item / cw) * G) * rv + c0 + item % cw;
+      u32x4 w[AR_MAX_RANKS];
+#pragma unroll
+      for (int r = 0; r < AR_MAX_RANKS; ++r)
+        if (r < P.world) w[r] = reinterpret_cast<const u32x4*>(P.region[r] + half)[idx];
+      float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int r = 0; r < AR_MAX_RANKS; ++r)
+        if (r < P.world) ar_accumulate<S>(acc, w[r]);
+      mine[idx] = ar_pack<S>(acc);
+    }
+  }
+  ar_barrier(P, seq + 2);
+
+  // 3. whole rows of the sum from their owners; add the residual, normalise
+  const float inv_hidden = 1.0f / (float)(rv * 8);
+  for (int row0 = b; row0 < rows; row0 += AR_ROW_CHUNK * G) {
+    u32x4 sum_w[AR_ROW_CHUNK][2], res_w[AR_ROW_CHUNK][2];
+#pragma unroll
+    for (int c = 0; c < AR_ROW_CHUNK; ++c) {
+      const int row = row0 + c * G;
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int v = t + k * AR_THREADS;
+        if (row < rows && v < rv) {
+          const int64_t idx = (int64_t)row * rv + v;
+          sum_w[c][k] = reinterpret_cast<const u32x4*>(P.region[v / cw] + half)[idx];
+          res_w[c][k] = residual[idx];
+        }
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < AR_ROW_CHUNK; ++c) {
+      const int row = row0 + c * G;
+      if (row >= rows) break;                     // uniform over the block
+      float x[2][8];
+      float var = 0.f;
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int v = t + k * AR_THREADS;
+        if (v < rv) {
+          float a[8], r[8];
+          ar_unpack<S>(sum_w[c][k], a);
+          ar_unpack<S>(res_w[c][k], r);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            x[k][e] = ar_rnd<S>(a[e] + r[e]);
+            var += x[k][e] * x[k][e];
+          }
+          residual[(int64_t)row * rv + v] = ar_pack<S>(x[k]);
+        }
+      }
+      var = ar_block_sum(var, red);
+      const float inv = rsqrtf(var * inv_hidden + eps);
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int v = t + k * AR_THREADS;
+        if (v < rv) {
+          float w[8], y[8];
+          ar_unpack<S>(weight[v], w);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) y[e] = ar_rnd<S>(x[k][e] * inv) * w[e];
+          out[(int64_t)row * rv + v] = ar_pack<S>(y);
+        }
+      }
+    }
+  }
+  if (threadIdx.x == 0) __hip_atomic_store(seq_slot, seq + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 }  // namespace
 }  // namespace vla
 
@@ -356,6 +488,39 @@ extern "C" int vla_ar_all_reduce_slabs(void* ctx, void* out, const float* slabs,
   else
     hipLaunchKernelGGL((xgmi_two_shot_kernel<BF16, true>), grid, block, 0, s, c->p, (u32x4*)out,
                        (const u32x4*)slabs, nvec, per, num_slabs, slab_stride);
+  VLA_HIP_CHECK(hipGetLastError());
+  return VLA_OK;
+}
+
+extern "C" int vla_ar_all_reduce_add_rms_norm(void* ctx, void* out, const void* in, int num_slabs,
+                                              int64_t slab_stride, void* residual,
+                                              const void* weight, float epsilon, int rows,
+                                              int hidden, int dtype, void* stream) {
+  (void)hipGetLastError();
+  ArContext* c = static_cast<ArContext*>(ctx);
+  if (!c || !out || !in || !residual || !weight || rows < 0 || hidden <= 0 || num_slabs < 0)
+    return VLA_ERR_ARG;
+  if (dtype != VLA_F16 && dtype != VLA_BF16) return VLA_ERR_DTYPE;
+  const int64_t numel = (int64_t)rows * hidden;
+  if (hidden % 8 || (hidden / 8) % c->p.world || hidden / 8 > 2 * AR_THREADS ||
+      numel * 2 > c->p.max_bytes)
+    return VLA_ERR_ARG;
+  if (((uintptr_t)out | (uintptr_t)in | (uintptr_t)residual | (uintptr_t)weight) % 16)
+    return VLA_ERR_ARG;
+  if (num_slabs > 0 && (slab_stride < numel || slab_stride % 4)) return VLA_ERR_ARG;
+  const int rv = hidden / 8;
+  dim3 grid(c->num_blocks), block(AR_THREADS);
+  hipStream_t s = (hipStream_t)stream;
+#define VLA_AR_NORM(S, SL)                                                                      \
+  hipLaunchKernelGGL((xgmi_two_shot_norm_kernel<S, SL>), grid, block, 0, s, c->p, (u32x4*)out,  \
+                     (const u32x4*)in, (u32x4*)residual, (const u32x4*)weight, epsilon, rows, rv, \
+                     num_slabs, slab_stride)
+  if (dtype == VLA_F16) {
+    if (num_slabs > 0) VLA_AR_NORM(F16, true); else VLA_AR_NORM(F16, false);
+  } else {
+    if (num_slabs > 0) VLA_AR_NORM(BF16, true); else VLA_AR_NORM(BF16, false);
+  }
+#undef VLA_AR_NORM
   VLA_HIP_CHECK(hipGetLastError());
   return VLA_OK;
 }

@@ -140,6 +140,34 @@ class XgmiAllReduce:
                 torch.cuda.current_stream(ws.device).cuda_stream), "ar_all_reduce_slabs")
         return out
 
+    def takes_add_rms_norm(self, m: int, n: int, dtype: torch.dtype) -> bool:
+        """Whether all_reduce_add_rms_norm can take an [m, n] message."""
+        return (self.takes_slabs(m, n, dtype) and n % 8 == 0 and (n // 8) % self.world_size == 0
+                and n // 8 <= 1024)
+
+    def all_reduce_add_rms_norm(self, x, residual: torch.Tensor, weight: torch.Tensor,
+                                epsilon: float) -> torch.Tensor:
+        """x: this rank's [m, n] partial output or its ops.SplitKSlabs.  residual is updated in
+        place with sum + residual; returns RMSNorm(residual) * weight."""
+        slabs = None if isinstance(x, torch.Tensor) else x
+        m, n = (x.shape if slabs is None else (slabs.m, slabs.n))
+        dtype = residual.dtype
+        assert self.takes_add_rms_norm(m, n, dtype) and residual.is_contiguous()
+        assert tuple(residual.shape) == (m, n) and weight.dtype == dtype and weight.numel() == n
+        if slabs is None:
+            assert x.dtype == dtype and x.is_contiguous()
+            src, ns = x, 0
+        else:
+            src, ns = slabs.workspace, slabs.num_slabs
+        out = torch.empty_like(residual)
+        code = {torch.float16: _lib.F16, torch.bfloat16: _lib.BF16}[dtype]
+        with torch.cuda.device(residual.device):
+            _lib.check(_lib.lib().vla_ar_all_reduce_add_rms_norm(
+                self._ctx, out.data_ptr(), src.data_ptr(), ns, m * n, residual.data_ptr(),
+                weight.data_ptr(), float(epsilon), m, n, code,
+                torch.cuda.current_stream(residual.device).cuda_stream), "ar_all_reduce_add_rms_norm")
+        return out
+
     def custom_all_reduce(self, input: torch.Tensor) -> Optional[torch.Tensor]:
         if self.disabled or not self.should_custom_ar(input):
             return None
