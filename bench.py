@@ -150,7 +150,8 @@ def select_all_reduce(device, world, rank, hidden, tokens, dtype):
     import torch.distributed as dist
     from vllm_legacy_amd.distributed import communication_op as co
     from vllm_legacy_amd.distributed import parallel_state as ps
-    rec = {"impl": "rccl", "xgmi_us": None, "rccl_us": None, "xgmi_verified": False, "note": ""}
+    rec = {"impl": "rccl", "xgmi_us": None, "rccl_us": None, "xgmi_verified": False,
+           "fused_norm": False, "note": ""}
     if os.environ.get("VLA_XGMI_ALLREDUCE", "auto") == "0":
         rec["note"] = "trial skipped"
         return rec
@@ -184,6 +185,23 @@ def select_all_reduce(device, world, rank, hidden, tokens, dtype):
                 if ok:
                     got = comm.all_reduce_slabs(slabs, dtype)
                     ok = torch.equal(got, comm.all_reduce(slabs.reduce(dtype).contiguous()))
+        # and the form that also does the add + RMSNorm after the all-reduce: residual bit for
+        # bit, normalised rows to the last place, against the separate launches; it is switched
+        # off on its own if it does not hold
+        norm_ok = False
+        if ok and co.FUSE_NORM and comm.takes_add_rms_norm(tokens, hidden, dtype):
+            from vllm_legacy_amd import _custom_ops as ops
+            norm_ok = True
+            for it in range(4):
+                x = torch.empty((tokens, hidden), dtype=dtype, device=device).uniform_(-1, 1, generator=g)
+                res0 = torch.empty_like(x).uniform_(-1, 1, generator=g)
+                w = torch.empty(hidden, dtype=dtype, device=device).uniform_(0.5, 1.5, generator=g)
+                plain, ra, rb = comm.all_reduce(x), res0.clone(), res0.clone()
+                ops.fused_add_rms_norm(plain, ra, w, 1e-5)
+                got = comm.all_reduce_add_rms_norm(x, rb, w, 1e-5)
+                ulp = 2.0**-10 if dtype == torch.float16 else 2.0**-7
+                norm_ok = norm_ok and torch.equal(ra, rb) and torch.allclose(
+                    got.float(), plain.float(), rtol=2 * ulp, atol=1e-6)
         ok = ok and comm.error_count() == 0
 
         def timed(fn):
@@ -202,12 +220,26 @@ def select_all_reduce(device, world, rank, hidden, tokens, dtype):
 
         t_x = timed(lambda x: comm.all_reduce(x, out=x))
         t_r = timed(co.tensor_model_parallel_all_reduce)
+        t_two = t_fused = 0.0
+        if norm_ok:      # the fused form has to earn its place against the two launches
+            from vllm_legacy_amd import _custom_ops as ops
+            res = torch.zeros((tokens, hidden), dtype=dtype, device=device)
+            w = torch.ones(hidden, dtype=dtype, device=device)
+            t_two = timed(lambda x: ops.fused_add_rms_norm(
+                comm.all_reduce(x.view(tokens, hidden)), res, w, 1e-5))
+            t_fused = timed(lambda x: comm.all_reduce_add_rms_norm(x.view(tokens, hidden), res, w, 1e-5))
         ok = ok and comm.error_count() == 0
         # one decision for the whole group: everybody verified, and the slowest rank's times
-        flags = torch.tensor([1.0 if ok else 0.0, -t_x, -t_r], dtype=torch.float64)
+        flags = torch.tensor([1.0 if ok else 0.0, -t_x, -t_r, 1.0 if norm_ok else 0.0, -t_two,
+                              -t_fused], dtype=torch.float64)
         dist.all_reduce(flags, op=dist.ReduceOp.MIN, group=cpu_group)
         ok, t_x, t_r = flags[0].item() == 1.0, -flags[1].item(), -flags[2].item()
-        rec.update(xgmi_verified=ok, xgmi_us=round(t_x, 1), rccl_us=round(t_r, 1))
+        t_two, t_fused = -flags[4].item(), -flags[5].item()
+        norm_ok = ok and flags[3].item() == 1.0
+        co.FUSE_NORM = co.FUSE_NORM and norm_ok and t_fused < t_two
+        rec.update(xgmi_verified=ok, xgmi_us=round(t_x, 1), rccl_us=round(t_r, 1),
+                   fused_norm=co.FUSE_NORM, fused_norm_verified=norm_ok,
+                   norm_two_launches_us=round(t_two, 1), norm_fused_us=round(t_fused, 1))
         if ok and t_x < t_r:
             ps.set_tp_xgmi_all_reduce(comm)
             rec["impl"] = "xgmi"

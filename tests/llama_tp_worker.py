@@ -1,7 +1,8 @@
 """One tensor-parallel rank of the Llama decode-stack test (started by test_gpu_fused.py; every
 rank on cuda:0, Gloo process groups).  Runs one decode step and saves rank 0's logits; with
 VLA_XGMI_ALLREDUCE=1 the row-parallel linears hand their unreduced split-K slabs to the
-peer-memory all-reduce, otherwise they reduce first and the all-reduce is staged through Gloo."""
+peer-memory all-reduce (which, unless VLA_XGMI_FUSE_NORM=0, also does the add + RMSNorm after
+it), otherwise they reduce first and the all-reduce is staged through Gloo."""
 import os
 import sys
 
@@ -31,15 +32,20 @@ def main():
         for lin in (layer.qkv_proj, layer.o_proj, layer.gate_up_proj, layer.down_proj):
             lin.scales.data = (lin.scales.data.float() * 0.1).half()
     # count how the all-reduce is fed
-    fed = {"slabs": 0, "tensors": 0}
-    inner = comm_op.tensor_model_parallel_all_reduce
+    fed = {"slabs": 0, "tensors": 0, "norm": 0}
+    from vllm_legacy_amd.distributed.xgmi_all_reduce import XgmiAllReduce
 
-    def counting(x, *a, **k):
-        fed["slabs" if isinstance(x, ops.SplitKSlabs) else "tensors"] += 1
-        return inner(x, *a, **k)
+    def counted(name, key):
+        inner = getattr(XgmiAllReduce, name)
 
-    import vllm_legacy_amd.model.llama_decode as ld
-    ld.tensor_model_parallel_all_reduce = counting
+        def wrapper(self, x, *a, **k):
+            fed[key(x)] += 1
+            return inner(self, x, *a, **k)
+        setattr(XgmiAllReduce, name, wrapper)
+
+    counted("all_reduce_slabs", lambda x: "slabs")
+    counted("all_reduce", lambda x: "tensors")
+    counted("all_reduce_add_rms_norm", lambda x: "norm")
 
     bs = 16
     seq_lens = np.array([1, 5, 16, 17, 100, 200, 37, 64] * 8, dtype=np.int32)       # 64 sequences
@@ -75,11 +81,15 @@ def main():
     xg = ps.get_tp_xgmi_all_reduce(dev)
     if os.environ.get("VLA_XGMI_ALLREDUCE") == "1":
         assert xg is not None and not xg.disabled and xg.error_count() == 0
-        assert fed["slabs"] > 0, fed          # the split-K layers went in unreduced
+        if os.environ.get("VLA_XGMI_FUSE_NORM", "1") == "0":
+            assert fed["slabs"] > 0 and fed["norm"] == 0, fed     # split-K layers went in unreduced
+        else:
+            assert fed["norm"] == 2 * cfg.num_hidden_layers and fed["slabs"] == 0, fed
     else:
-        assert xg is None and fed["slabs"] == 0, fed
+        assert xg is None and fed["slabs"] + fed["norm"] + fed["tensors"] == 0, fed
     if rank == 0:
-        np.savez(out_path, logits=logits.float().cpu().numpy(), slabs=fed["slabs"], tensors=fed["tensors"])
+        np.savez(out_path, logits=logits.float().cpu().numpy(), slabs=fed["slabs"], tensors=fed["tensors"],
+                 norm=fed["norm"])
     dist.barrier()
     ps.destroy_model_parallel()
     dist.destroy_process_group()

@@ -124,18 +124,19 @@ def test_partial_gemm_slabs_reduce_to_the_full_result(ops, k, n):
     assert torch.equal(got, full)
 
 
-def _run_llama_tp(tmp_path, world, xgmi):
+def _run_llama_tp(tmp_path, world, xgmi, fuse_norm=True):
     import socket
     import subprocess
     import sys
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    out = str(tmp_path / f"llama_tp_{int(xgmi)}.npz")
+    out = str(tmp_path / f"llama_tp_{int(xgmi)}{int(fuse_norm)}.npz")
     here = os.path.dirname(os.path.abspath(__file__))
     procs = [subprocess.Popen([sys.executable, "-u", os.path.join(here, "llama_tp_worker.py"), str(r), str(world),
                                str(port), out], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
                               env=dict(os.environ, VLA_XGMI_ALLREDUCE="1" if xgmi else "0",
+                                       VLA_XGMI_FUSE_NORM="1" if fuse_norm else "0",
                                        HSA_ENABLE_IPC_MODE_LEGACY="0"))
              for r in range(world)]
     try:
@@ -149,14 +150,19 @@ def _run_llama_tp(tmp_path, world, xgmi):
     return np.load(out)
 
 
-def test_tensor_parallel_step_with_slabs_into_the_peer_memory_all_reduce(tmp_path):
-    """Two ranks on one GPU, one decode step of a two-layer stack.  With the peer-memory
-    all-reduce the row-parallel linears leave their split-K slabs unreduced and the all-reduce
-    sums them while publishing; without it they reduce first and the sum is staged through Gloo.
-    Each rank's contribution is rounded to fp16 once either way and a two-rank sum has a single
-    rounding, so the logits agree bit for bit."""
-    a = _run_llama_tp(tmp_path, 2, xgmi=True)
-    b = _run_llama_tp(tmp_path, 2, xgmi=False)
-    assert int(a["slabs"]) > 0 and int(b["slabs"]) == 0
+def test_tensor_parallel_step_through_the_peer_memory_all_reduce(tmp_path):
+    """Two ranks on one GPU, one decode step of a two-layer stack, three ways.  (a) Gloo: the
+    row-parallel linears reduce their split-K slabs, the sum is staged through the host.  (b) the
+    peer-memory all-reduce fed with the unreduced slabs: each rank's contribution is rounded to
+    fp16 once either way and a two-rank sum has a single rounding, so the logits equal (a) bit for
+    bit.  (c) the all-reduce also doing the add + RMSNorm that follows it: the sum of squares is
+    accumulated in another order, so normalised values may move in the last place and the logits
+    agree to a few fp16 units."""
+    a = _run_llama_tp(tmp_path, 2, xgmi=False)
+    b = _run_llama_tp(tmp_path, 2, xgmi=True, fuse_norm=False)
+    c = _run_llama_tp(tmp_path, 2, xgmi=True, fuse_norm=True)
+    assert int(b["slabs"]) > 0 and int(b["norm"]) == 0 and int(c["norm"]) == 4
     assert np.isfinite(a["logits"]).all() and float(np.abs(a["logits"]).max()) > 0.1
     assert np.array_equal(a["logits"], b["logits"])
+    np.testing.assert_allclose(c["logits"], a["logits"], atol=2e-2, rtol=1e-2)
+    assert float(np.mean(c["logits"] != a["logits"])) < 0.5

@@ -143,10 +143,37 @@ def main():
     e1.record()
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 1000 / 50
+    # the same message followed by add + RMSNorm: two launches against the fused one
+    us_two = us_fused = None
+    if comm.takes_add_rms_norm(256, 4096, torch.float16):
+        xm = torch.zeros((256, 4096), dtype=torch.float16, device=dev)
+        res = torch.zeros_like(xm)
+        wgt = torch.ones(4096, dtype=torch.float16, device=dev)
+
+        def two():
+            ops.fused_add_rms_norm(comm.all_reduce(xm), res, wgt, 1e-5)
+
+        def fused():
+            comm.all_reduce_add_rms_norm(xm, res, wgt, 1e-5)
+
+        times = []
+        for fn in (two, fused):
+            for _ in range(5):
+                fn()
+            torch.cuda.synchronize()
+            dist.barrier()
+            e0.record()
+            for _ in range(50):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            times.append(round(e0.elapsed_time(e1) * 1000 / 50, 1))
+        us_two, us_fused = times
     errors = comm.error_count()
     comm.close()
     print(json.dumps({"rank": rank, "world": world, "ok": errors == 0, "timeouts": errors,
-                      "us_per_2MiB_call_same_gpu": round(us, 1)}), flush=True)
+                      "us_per_2MiB_call_same_gpu": round(us, 1), "us_with_norm_two_launches": us_two,
+                      "us_with_norm_fused": us_fused}), flush=True)
     dist.destroy_process_group()
     sys.exit(0 if errors == 0 else 3)
 

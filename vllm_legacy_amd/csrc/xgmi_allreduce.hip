@@ -224,18 +224,6 @@ __device__ __forceinline__ void ar_unpack(const u32x4 w, float (&f)[8]) {
 template <class S>
 __device__ __forceinline__ float ar_rnd(float v) { return S::to_f32(S::from_f32(v)); }
 
-// Sum of one value per thread over the workgroup (AR_THREADS threads).
-__device__ __forceinline__ float ar_block_sum(float v, float* red) {
-  v = wave_sum(v);
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
-  __syncthreads();
-  float r = 0.f;
-#pragma unroll
-  for (int i = 0; i < AR_THREADS / 64; ++i) r += red[i];
-  __syncthreads();
-  return r;
-}
-
 // The all-reduce followed by the layer's next step, residual = sum + residual and
 // out = RMSNorm(residual) * weight (csrc/layernorm_kernels.cu:52-91, the pair
 // vllm/model_executor/models/llama.py:213-224 runs after each row-parallel linear), in one launch.
@@ -244,12 +232,12 @@ __device__ __forceinline__ float ar_block_sum(float v, float* red) {
 // covers every dependency), rank r reduces the r-th column range of each row, and in step 3 a
 // block holds whole rows of the sum, which is what the normalisation needs.
 // rv: 16-byte units per row (hidden / 8), a multiple of the world size, at most 2 * AR_THREADS.
-constexpr int AR_ROW_CHUNK = 4;   // rows whose loads are in flight together in step 3
+constexpr int AR_ROW_CHUNK = 8;   // rows whose loads are in flight together in step 3
 template <class S, bool SLABS>
 __global__ __launch_bounds__(AR_THREADS) void xgmi_two_shot_norm_kernel(
     ArParams P, u32x4* out, const u32x4* in, u32x4* residual, const u32x4* weight, float eps,
     int rows, int rv, int num_slabs, int64_t slab_stride) {
-  __shared__ float red[AR_THREADS / 64];
+  __shared__ float red[AR_ROW_CHUNK][AR_THREADS / 64];
   unsigned char* self = P.region[P.rank];
   uint32_t* seq_slot = reinterpret_cast<uint32_t*>(self + AR_SEQ_OFF) + blockIdx.x;
   const uint32_t seq = __hip_atomic_load(seq_slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -287,8 +275,10 @@ __global__ __launch_bounds__(AR_THREADS) void xgmi_two_shot_norm_kernel(
   }
   ar_barrier(P, seq + 2);
 
-  // 3. whole rows of the sum from their owners; add the residual, normalise
+  // 3. whole rows of the sum from their owners; add the residual, normalise.  A chunk of rows
+  // has all its loads in flight together and shares one reduction of its sums of squares.
   const float inv_hidden = 1.0f / (float)(rv * 8);
+  const int lane = t & 63, wv = t >> 6;
   for (int row0 = b; row0 < rows; row0 += AR_ROW_CHUNK * G) {
     u32x4 sum_w[AR_ROW_CHUNK][2], res_w[AR_ROW_CHUNK][2];
 #pragma unroll
@@ -304,41 +294,52 @@ __global__ __launch_bounds__(AR_THREADS) void xgmi_two_shot_norm_kernel(
         }
       }
     }
+    // x = sum + residual (kept as packed model-dtype words), per-row sums of squares
 #pragma unroll
     for (int c = 0; c < AR_ROW_CHUNK; ++c) {
       const int row = row0 + c * G;
-      if (row >= rows) break;                     // uniform over the block
-      float x[2][8];
       float var = 0.f;
 #pragma unroll
       for (int k = 0; k < 2; ++k) {
         const int v = t + k * AR_THREADS;
-        if (v < rv) {
-          float a[8], r[8];
+        if (row < rows && v < rv) {
+          float a[8], r[8], x[8];
           ar_unpack<S>(sum_w[c][k], a);
           ar_unpack<S>(res_w[c][k], r);
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
-            x[k][e] = ar_rnd<S>(a[e] + r[e]);
-            var += x[k][e] * x[k][e];
+            x[e] = ar_rnd<S>(a[e] + r[e]);
+            var += x[e] * x[e];
           }
-          residual[(int64_t)row * rv + v] = ar_pack<S>(x[k]);
+          sum_w[c][k] = ar_pack<S>(x);
+          residual[(int64_t)row * rv + v] = sum_w[c][k];
         }
       }
-      var = ar_block_sum(var, red);
+      var = wave_sum(var);
+      if (lane == 0) red[c][wv] = var;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < AR_ROW_CHUNK; ++c) {
+      const int row = row0 + c * G;
+      float var = 0.f;
+#pragma unroll
+      for (int i = 0; i < AR_THREADS / 64; ++i) var += red[c][i];
       const float inv = rsqrtf(var * inv_hidden + eps);
 #pragma unroll
       for (int k = 0; k < 2; ++k) {
         const int v = t + k * AR_THREADS;
-        if (v < rv) {
-          float w[8], y[8];
+        if (row < rows && v < rv) {
+          float x[8], w[8], y[8];
+          ar_unpack<S>(sum_w[c][k], x);
           ar_unpack<S>(weight[v], w);
 #pragma unroll
-          for (int e = 0; e < 8; ++e) y[e] = ar_rnd<S>(x[k][e] * inv) * w[e];
+          for (int e = 0; e < 8; ++e) y[e] = ar_rnd<S>(x[e] * inv) * w[e];
           out[(int64_t)row * rv + v] = ar_pack<S>(y);
         }
       }
     }
+    __syncthreads();                                   // red is reused by the next chunk
   }
   if (threadIdx.x == 0) __hip_atomic_store(seq_slot, seq + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }

@@ -8,6 +8,7 @@ peer-memory all-reduce of xgmi_all_reduce.py as an opt-in for the hot one.  The 
 all-reduce is the [tokens, hidden] partial output of a row-parallel linear (2 MiB for
 Llama-3-8B at 256 tokens), issued in place on the compute stream.
 """
+import os
 from typing import Any, Dict, Optional
 
 import torch
@@ -29,6 +30,43 @@ def tensor_model_parallel_takes_slabs(m: int, n: int, dtype: torch.dtype, device
         return True
     xgmi = get_tp_xgmi_all_reduce(device)
     return xgmi is not None and xgmi.takes_slabs(m, n, dtype)
+
+
+# VLA_XGMI_FUSE_NORM=0 (or setting this to False) keeps the all-reduce and the add + RMSNorm after
+# it as separate launches even when the peer-memory all-reduce could do both.
+FUSE_NORM = os.environ.get("VLA_XGMI_FUSE_NORM", "1") != "0"
+
+
+class PendingAllReduce:
+    """The output of a row-parallel linear (a tensor, or ops.SplitKSlabs) whose all-reduce has
+    been left to the add + RMSNorm that consumes it (layers.RMSNorm accepts one)."""
+
+    def __init__(self, value):
+        self.value = value
+
+
+def tensor_model_parallel_fuses_norm(m: int, n: int, dtype: torch.dtype, device) -> bool:
+    """Whether an [m, n] row-parallel output may be wrapped in PendingAllReduce: several ranks
+    and a peer-memory all-reduce that takes the message together with the normalisation."""
+    if not FUSE_NORM or get_tensor_model_parallel_world_size() == 1:
+        return False
+    xgmi = get_tp_xgmi_all_reduce(device)
+    return xgmi is not None and xgmi.takes_add_rms_norm(m, n, dtype)
+
+
+def tensor_model_parallel_all_reduce_add_rms_norm(pending: PendingAllReduce, residual: torch.Tensor,
+                                                  weight: torch.Tensor, epsilon: float):
+    """all-reduce, residual += sum, RMSNorm(residual) * weight; returns (normed, residual).  One
+    launch on the peer-memory all-reduce, the separate steps otherwise."""
+    from .. import _custom_ops as ops
+    x = pending.value
+    m, n = residual.shape
+    if tensor_model_parallel_fuses_norm(m, n, residual.dtype, residual.device):
+        xgmi = get_tp_xgmi_all_reduce(residual.device)
+        return xgmi.all_reduce_add_rms_norm(x, residual, weight, epsilon), residual
+    hidden = tensor_model_parallel_all_reduce(x, residual.dtype)
+    ops.fused_add_rms_norm(hidden, residual, weight, epsilon)
+    return hidden, residual
 
 
 def tensor_model_parallel_all_reduce(input_, dtype: torch.dtype = torch.float16) -> torch.Tensor:

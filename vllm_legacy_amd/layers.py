@@ -12,6 +12,8 @@ import torch
 import torch.nn as nn
 
 from vllm_legacy_amd import _custom_ops as ops
+from vllm_legacy_amd.distributed.communication_op import (
+    PendingAllReduce, tensor_model_parallel_all_reduce_add_rms_norm)
 
 
 class RMSNorm(nn.Module):
@@ -24,6 +26,11 @@ class RMSNorm(nn.Module):
 
     def forward(self, x, residual: Optional[torch.Tensor] = None
                 ) -> Union[torch.Tensor, Tuple[torch.Tensor, torch.Tensor]]:
+        if isinstance(x, PendingAllReduce):
+            # a row-parallel linear's output under tensor parallelism: the all-reduce happens here
+            assert residual is not None
+            return tensor_model_parallel_all_reduce_add_rms_norm(x, residual, self.weight.data,
+                                                                 self.variance_epsilon)
         if isinstance(x, ops.SplitKSlabs):
             # the producing GEMM left its split-K partial sums for this kernel to add up
             assert residual is not None

@@ -19,7 +19,9 @@ import torch.nn as nn
 from vllm_legacy_amd import _custom_ops as ops
 from vllm_legacy_amd.attention.layer import Attention
 from vllm_legacy_amd.attention.ops.paged_attn import PagedAttention
-from vllm_legacy_amd.distributed.communication_op import (tensor_model_parallel_all_reduce,
+from vllm_legacy_amd.distributed.communication_op import (PendingAllReduce,
+                                                          tensor_model_parallel_all_reduce,
+                                                          tensor_model_parallel_fuses_norm,
                                                           tensor_model_parallel_gather,
                                                           tensor_model_parallel_takes_slabs)
 from vllm_legacy_amd.distributed.parallel_state import (get_tensor_model_parallel_rank,
@@ -151,14 +153,17 @@ class LlamaDecodeLayer(nn.Module):
             attn_out = self.attn(q, k, v, kv_cache, attn_metadata)
         # Split-K slabs of the row-parallel linears are left unreduced when the next step can sum
         # them itself: the add + RMSNorm kernel on a single rank, the peer-memory all-reduce with
-        # several (RCCL needs the finished tensor).
-        fuse = tensor_model_parallel_takes_slabs(hidden.shape[0], self.cfg.hidden_size, hidden.dtype,
-                                                 hidden.device)
-        hidden = tensor_model_parallel_all_reduce(self.o_proj(attn_out, defer_reduce=fuse),
-                                                  hidden.dtype)
+        # several (RCCL needs the finished tensor).  With that all-reduce in place it also does
+        # the add + RMSNorm that follows: the linear's output travels on as a PendingAllReduce,
+        # to this layer's second norm, the next layer's first or the model's final one.
+        tokens, dt, dev = hidden.shape[0], hidden.dtype, hidden.device
+        fuse = tensor_model_parallel_takes_slabs(tokens, self.cfg.hidden_size, dt, dev)
+        fuse_norm = tensor_model_parallel_fuses_norm(tokens, self.cfg.hidden_size, dt, dev)
+        hidden = self.o_proj(attn_out, defer_reduce=fuse)
+        hidden = PendingAllReduce(hidden) if fuse_norm else tensor_model_parallel_all_reduce(hidden, dt)
         hidden, residual = self.post_attention_layernorm(hidden, residual)
-        hidden = tensor_model_parallel_all_reduce(
-            self.down_proj(self.act_fn(self.gate_up_proj(hidden)), defer_reduce=fuse), hidden.dtype)
+        hidden = self.down_proj(self.act_fn(self.gate_up_proj(hidden)), defer_reduce=fuse)
+        hidden = PendingAllReduce(hidden) if fuse_norm else tensor_model_parallel_all_reduce(hidden, dt)
         return hidden, residual
 
 
