@@ -163,6 +163,13 @@ def select_all_reduce(device, world, rank, hidden, tokens, dtype):
         if comm.disabled:
             rec["note"] = comm.reason
             return rec
+        def agree(flag: bool) -> bool:
+            """The same answer on every rank: the calls below are collective, so whether they
+            are made must not depend on what one rank saw."""
+            t = torch.tensor([1.0 if flag else 0.0], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN, group=cpu_group)
+            return t.item() == 1.0
+
         ok = True
         g = torch.Generator(device=device).manual_seed(1234 + rank)
         for it in range(24):
@@ -174,24 +181,36 @@ def select_all_reduce(device, world, rank, hidden, tokens, dtype):
                 want += parts[r].float()
             got = comm.all_reduce(x)
             ok = ok and torch.equal(got, want.to(dtype))
+            # a barrier that cannot see its peers only gives up after seconds of polling: stop at
+            # the first sign instead of sitting through every remaining call
+            if it in (0, 1, 7) and not agree(comm.error_count() == 0):
+                ok = False
+                break
+        ok = agree(ok and comm.error_count() == 0)
+        if not ok:
+            rec["note"] = "results differed or a barrier timed out"
+            return rec
         # the form the row-parallel linears use: unreduced split-K slabs as the input
-        if dtype in (torch.float16, torch.bfloat16):
+        slabs_ok = dtype in (torch.float16, torch.bfloat16) and comm.takes_slabs(tokens, hidden, dtype)
+        if slabs_ok:
             from vllm_legacy_amd._custom_ops import SplitKSlabs
             for ns in (2, 8):
                 ws = torch.empty(ns * tokens * hidden, dtype=torch.float32,
                                  device=device).uniform_(-1, 1, generator=g)
                 slabs = SplitKSlabs(ws.view(torch.uint8), ns, tokens, hidden)
-                ok = ok and comm.takes_slabs(tokens, hidden, dtype)
-                if ok:
-                    got = comm.all_reduce_slabs(slabs, dtype)
-                    ok = torch.equal(got, comm.all_reduce(slabs.reduce(dtype).contiguous()))
+                got = comm.all_reduce_slabs(slabs, dtype)
+                slabs_ok = slabs_ok and torch.equal(
+                    got, comm.all_reduce(slabs.reduce(dtype).contiguous()))
+        ok = agree(slabs_ok and comm.error_count() == 0)
+        if not ok:
+            rec["note"] = "the slab form differed or a barrier timed out"
+            return rec
         # and the form that also does the add + RMSNorm after the all-reduce: residual bit for
         # bit, normalised rows to the last place, against the separate launches; it is switched
         # off on its own if it does not hold
-        norm_ok = False
-        if ok and co.FUSE_NORM and comm.takes_add_rms_norm(tokens, hidden, dtype):
+        norm_ok = co.FUSE_NORM and comm.takes_add_rms_norm(tokens, hidden, dtype)
+        if norm_ok:
             from vllm_legacy_amd import _custom_ops as ops
-            norm_ok = True
             for it in range(4):
                 x = torch.empty((tokens, hidden), dtype=dtype, device=device).uniform_(-1, 1, generator=g)
                 res0 = torch.empty_like(x).uniform_(-1, 1, generator=g)
@@ -202,7 +221,8 @@ def select_all_reduce(device, world, rank, hidden, tokens, dtype):
                 ulp = 2.0**-10 if dtype == torch.float16 else 2.0**-7
                 norm_ok = norm_ok and torch.equal(ra, rb) and torch.allclose(
                     got.float(), plain.float(), rtol=2 * ulp, atol=1e-6)
-        ok = ok and comm.error_count() == 0
+        norm_ok = agree(norm_ok)
+        ok = agree(comm.error_count() == 0)
 
         def timed(fn):
             x = torch.zeros(tokens * hidden, dtype=dtype, device=device)
@@ -246,6 +266,8 @@ def select_all_reduce(device, world, rank, hidden, tokens, dtype):
             comm = None
         elif not ok:
             rec["note"] = "results differed or a barrier timed out"
+        if rec["impl"] != "xgmi":
+            rec["fused_norm"] = False
     except Exception as e:  # noqa: BLE001
         rec["note"] = f"{type(e).__name__}: {str(e).splitlines()[0] if str(e) else ''}"
     finally:
