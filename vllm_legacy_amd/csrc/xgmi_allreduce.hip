@@ -233,7 +233,11 @@ __device__ __forceinline__ float ar_rnd(float v) { return S::to_f32(S::from_f32(
 // block holds whole rows of the sum, which is what the normalisation needs.
 // rv: 16-byte units per row (hidden / 8), a multiple of the world size, at most 2 * AR_THREADS.
 constexpr int AR_ROW_CHUNK = 8;   // rows whose loads are in flight together in step 3
-template <class S, bool SLABS>
+// PAIR (two ranks): step 2 and its barrier are dropped -- step 3 reads the row from both staging
+// halves and sums it itself (rank order, the same bits), which moves the same number of bytes
+// over the link as reduce + gather do.  The barrier count still advances by two per call, so
+// calls of both kinds can follow each other on one communicator.
+template <class S, bool SLABS, bool PAIR>
 __global__ __launch_bounds__(AR_THREADS) void xgmi_two_shot_norm_kernel(
     ArParams P, u32x4* out, const u32x4* in, u32x4* residual, const u32x4* weight, float eps,
     int rows, int rv, int num_slabs, int64_t slab_stride) {
@@ -254,11 +258,11 @@ __global__ __launch_bounds__(AR_THREADS) void xgmi_two_shot_norm_kernel(
     else
       for (int v = t; v < rv; v += AR_THREADS) mine[r0 + v] = in[r0 + v];
   }
-  ar_barrier(P, seq + 1);
+  ar_barrier(P, PAIR ? seq + 2 : seq + 1);
 
   // 2. this rank's column range of this block's rows, summed over the ranks in place
   const int cw = rv / P.world, c0 = P.rank * cw;
-  {
+  if constexpr (!PAIR) {
     const int my_rows = b < rows ? (rows - b + G - 1) / G : 0;
     for (int item = t; item < my_rows * cw; item += AR_THREADS) {
       const int64_t idx = (int64_t)(b + (item / cw) * G) * rv + c0 + item % cw;
@@ -272,8 +276,8 @@ __global__ __launch_bounds__(AR_THREADS) void xgmi_two_shot_norm_kernel(
         if (r < P.world) ar_accumulate<S>(acc, w[r]);
       mine[idx] = ar_pack<S>(acc);
     }
+    ar_barrier(P, seq + 2);
   }
-  ar_barrier(P, seq + 2);
 
   // 3. whole rows of the sum from their owners; add the residual, normalise.  A chunk of rows
   // has all its loads in flight together and shares one reduction of its sums of squares.
@@ -289,7 +293,16 @@ __global__ __launch_bounds__(AR_THREADS) void xgmi_two_shot_norm_kernel(
         const int v = t + k * AR_THREADS;
         if (row < rows && v < rv) {
           const int64_t idx = (int64_t)row * rv + v;
-          sum_w[c][k] = reinterpret_cast<const u32x4*>(P.region[v / cw] + half)[idx];
+          if constexpr (PAIR) {
+            const u32x4 w0 = reinterpret_cast<const u32x4*>(P.region[0] + half)[idx];
+            const u32x4 w1 = reinterpret_cast<const u32x4*>(P.region[1] + half)[idx];
+            float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            ar_accumulate<S>(acc, w0);
+            ar_accumulate<S>(acc, w1);
+            sum_w[c][k] = ar_pack<S>(acc);
+          } else {
+            sum_w[c][k] = reinterpret_cast<const u32x4*>(P.region[v / cw] + half)[idx];
+          }
           res_w[c][k] = residual[idx];
         }
       }
@@ -513,9 +526,16 @@ extern "C" int vla_ar_all_reduce_add_rms_norm(void* ctx, void* out, const void* 
   dim3 grid(c->num_blocks), block(AR_THREADS);
   hipStream_t s = (hipStream_t)stream;
 #define VLA_AR_NORM(S, SL)                                                                      \
-  hipLaunchKernelGGL((xgmi_two_shot_norm_kernel<S, SL>), grid, block, 0, s, c->p, (u32x4*)out,  \
-                     (const u32x4*)in, (u32x4*)residual, (const u32x4*)weight, epsilon, rows, rv, \
-                     num_slabs, slab_stride)
+  do {                                                                                          \
+    if (c->p.world == 2)                                                                        \
+      hipLaunchKernelGGL((xgmi_two_shot_norm_kernel<S, SL, true>), grid, block, 0, s, c->p,     \
+                         (u32x4*)out, (const u32x4*)in, (u32x4*)residual, (const u32x4*)weight, \
+                         epsilon, rows, rv, num_slabs, slab_stride);                            \
+    else                                                                                        \
+      hipLaunchKernelGGL((xgmi_two_shot_norm_kernel<S, SL, false>), grid, block, 0, s, c->p,    \
+                         (u32x4*)out, (const u32x4*)in, (u32x4*)residual, (const u32x4*)weight, \
+                         epsilon, rows, rv, num_slabs, slab_stride);                            \
+  } while (0)
   if (dtype == VLA_F16) {
     if (num_slabs > 0) VLA_AR_NORM(F16, true); else VLA_AR_NORM(F16, false);
   } else {
