@@ -519,6 +519,24 @@ static Q4Shape pick_shape(int m, int n, int k, int group) {
     want = (512 + wgs - 1) / wgs;
     if (want > 8) want = 8;
     if (want > k / (4 * TK)) want = k / (4 * TK);
+  } else if (m <= 256 && k < 4096 && ((n + 127) / 128) * ((m + 31) / 32) >= 192) {
+    // Short contractions over many columns (the row-parallel layers of a tensor-parallel rank:
+    // o_proj 512..2048 x 4096, down_proj 1792..3584 x 4096): a workgroup's loop is a few dozen
+    // steps at most, so its fixed cost and the tail of the launch decide.  Smaller row tiles
+    // fill the chip without slicing K, which also spares the slabs and their reduction:
+    // 512 x 4096 9.6 -> 5.4 us, 1024 x 4096 17.3 -> 8.3, 2048 x 4096 22.6 -> 13.8,
+    // 1792 x 4096 20.2 -> 12.2, 3584 x 4096 23.6 -> 21.5 (batch 256).  The largest tile height
+    // that still gives 192 workgroups is taken.
+    s.mt = ((n + 127) / 128) * ((m + 63) / 64) >= 192 ? 2 : 1;
+    s.nw = 4;
+    want = 1;
+  } else if (m <= 256 && n <= 2048 && k >= 2048) {
+    // Few columns, long contraction (qkv_proj of a tensor-parallel rank: 4096 x 768 / 1536):
+    // four K slices of small row tiles instead of eight slices of 128-row tiles
+    // (768 columns 16.5 -> 11.6 us, 1536 columns 19.5 -> 15.6).
+    s.mt = n <= 1024 ? 1 : 2;
+    s.nw = 4;
+    want = 4;
   } else {
     s.nw = (n < 3072 || k <= 2048) ? 4 : 8;
     const int wgs = ((n + 32 * s.nw - 1) / (32 * s.nw)) * mtiles;
