@@ -537,6 +537,12 @@ static Q4Shape pick_shape(int m, int n, int k, int group) {
     s.mt = n <= 1024 ? 1 : 2;
     s.nw = 4;
     want = 4;
+  } else if (m <= 256 && n < 4096 && k >= 4096 && k <= 8192) {
+    // fewer than 4096 columns over a long contraction (gate_up of an 8-way rank, 4096 x 3584:
+    // 24.3 -> 21.4 us)
+    s.mt = 2;
+    s.nw = 4;
+    want = 4;
   } else {
     s.nw = (n < 3072 || k <= 2048) ? 4 : 8;
     const int wgs = ((n + 32 * s.nw - 1) / (32 * s.nw)) * mtiles;
