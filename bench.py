@@ -48,6 +48,9 @@ def parse():
     ap.add_argument("--model", default="llama3-8b", choices=["llama3-8b", "llama3-70b", "tiny"])
     ap.add_argument("--no-graph", action="store_true", help="run the step eagerly")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--rank-of", type=int, default=1,
+                    help="kernel study: one process with the per-GPU shapes of an N-way tensor-"
+                         "parallel rank (heads, FFN and vocabulary divided by N, no collectives)")
     ap.add_argument("--attn-only", action="store_true",
                     help="time only the paged-attention launches (kernel study)")
     return ap.parse_args()
@@ -310,6 +313,12 @@ def main():
     cfg = {"llama3-8b": LlamaConfig.llama3_8b, "llama3-70b": LlamaConfig.llama3_70b,
            "tiny": LlamaConfig.tiny}[args.model]()
     cfg.num_hidden_layers = args.layers
+    if args.rank_of > 1:
+        assert world == 1
+        cfg.num_attention_heads //= args.rank_of
+        cfg.num_key_value_heads = max(1, cfg.num_key_value_heads // args.rank_of)
+        cfg.intermediate_size //= args.rank_of
+        cfg.vocab_size //= args.rank_of
     B, S, BS = args.batch, args.seq, 16
     torch.manual_seed(0)
     model_dtype = torch.float16 if args.dtype == "f16" else torch.bfloat16
@@ -548,7 +557,8 @@ def main():
                                else f"{args.dtype} weights")
                             + f", {args.kv if args.kv == 'fp8' else args.dtype} KV cache, "
                             f"batch {B}, context {S}, block 16, {args.layers} layers",
-                "parallelism": f"tp{world}",
+                "parallelism": (f"tp{world}" if args.rank_of == 1 else
+                                f"compute of one rank of tp{args.rank_of}, no collectives (study)"),
                 "graph": graph is not None,
                 "all_reduce": ar_rec,
                 "global_batch": B,
