@@ -367,6 +367,12 @@ int vla_fused_add_rms_norm_splitk(const float* slabs, int num_slabs, int64_t sla
                                   void* residual, const void* weight, float epsilon,
                                   int num_tokens, int hidden_size, int dtype, void* stream);
 
+/* silu_and_mul (csrc/ops.h:62-64) whose input arrives as split-K slabs
+ * [num_slabs][num_tokens][2 d] fp32: x = model_dtype(sum of slabs); out[t, j] = silu(x[t, j]) *
+ * x[t, d + j].  Same bits as reducing first. */
+int vla_silu_and_mul_splitk(const float* slabs, int num_slabs, int64_t slab_stride, void* out,
+                            int num_tokens, int d, int dtype, void* stream);
+
 /* Replaces get_max_shared_memory_per_block_device_attribute
  * (csrc/cuda_utils_kernels.cu:17-29). Returns bytes, or -1. */
 int vla_get_max_shared_memory_per_block(int device);

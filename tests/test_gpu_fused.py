@@ -166,3 +166,25 @@ def test_tensor_parallel_step_through_the_peer_memory_all_reduce(tmp_path):
     assert np.array_equal(a["logits"], b["logits"])
     np.testing.assert_allclose(c["logits"], a["logits"], atol=2e-2, rtol=1e-2)
     assert float(np.mean(c["logits"] != a["logits"])) < 0.5
+
+
+@pytest.mark.parametrize("dt", [O.DT_F16, O.DT_BF16])
+@pytest.mark.parametrize("tokens,d,ns", [(1, 64, 2), (37, 448, 3), (256, 3584, 4), (64, 14336, 2)])
+def test_silu_and_mul_fed_by_slabs(ops, dt, tokens, d, ns):
+    """SiLU·mul on unreduced split-K slabs against reduce-then-activate: the same sums, the same
+    rounding, the same arithmetic -- equal bits; and against the oracle's activation."""
+    from vllm_legacy_amd._custom_ops import SplitKSlabs
+    g = torch.Generator(device="cuda").manual_seed(tokens + d)
+    ws = torch.empty((ns, tokens, 2 * d), dtype=torch.float32, device="cuda").uniform_(-2, 2, generator=g)
+    slabs = SplitKSlabs(ws.view(-1).view(torch.uint8), ns, tokens, 2 * d)
+    tdt = torch.float16 if dt == O.DT_F16 else torch.bfloat16
+    got = torch.empty((tokens, d), dtype=tdt, device="cuda")
+    ops.silu_and_mul_splitk(slabs, got)
+    reduced = slabs.reduce(tdt).contiguous()
+    want = torch.empty_like(got)
+    ops.silu_and_mul(want, reduced)
+    torch.cuda.synchronize()
+    assert torch.equal(got.view(torch.int16), want.view(torch.int16))
+    ref = O.silu_and_mul(T.bits(reduced), dt)
+    np.testing.assert_allclose(got.float().cpu().numpy(), O.from_bits(ref, dt), rtol=2.0**-7 if dt == O.DT_BF16 else 2.0**-10,
+                               atol=1e-6)

@@ -582,6 +582,19 @@ def fused_add_rms_norm_splitk(slabs: SplitKSlabs, out: torch.Tensor, residual: t
             "fused_add_rms_norm_splitk")
 
 
+def silu_and_mul_splitk(slabs: SplitKSlabs, out: torch.Tensor) -> None:
+    """silu_and_mul whose input [tokens, 2 d] is the unreduced product `slabs` (summed and rounded
+    to out's dtype first): out [tokens, d]."""
+    _require_cuda(out)
+    assert out.is_contiguous() and out.dim() == 2
+    t, d = out.shape
+    assert slabs.m == t and slabs.n == 2 * d
+    with torch.cuda.device(out.device):
+        check(_lib.lib().vla_silu_and_mul_splitk(
+            slabs.workspace.data_ptr(), slabs.num_slabs, slabs.m * slabs.n, out.data_ptr(), t, d,
+            _dt(out), _stream(out.device)), "silu_and_mul_splitk")
+
+
 def gptq_gemm(a: torch.Tensor, b_q_weight: torch.Tensor, b_gptq_qzeros: torch.Tensor,
               b_gptq_scales: torch.Tensor, b_g_idx: torch.Tensor, use_exllama: bool,
               bit: int) -> torch.Tensor:

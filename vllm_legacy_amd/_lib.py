@@ -32,7 +32,7 @@ EXPORTS = [
     "vla_prefill_attention", "vla_prefix_prefill_attention", "vla_ar_region_bytes", "vla_ar_alloc_region",
     "vla_ar_free_region", "vla_ar_export", "vla_ar_import", "vla_ar_unimport", "vla_ar_create", "vla_ar_destroy",
     "vla_ar_all_reduce", "vla_ar_all_reduce_slabs", "vla_ar_all_reduce_add_rms_norm", "vla_ar_error_count", "vla_q4_gemm_grouped", "vla_q4_gemm_grouped_workspace_bytes",
-    "vla_q4_gemm_packed_partial", "vla_rotary_reshape_and_cache", "vla_fused_add_rms_norm_splitk",
+    "vla_q4_gemm_packed_partial", "vla_rotary_reshape_and_cache", "vla_fused_add_rms_norm_splitk", "vla_silu_and_mul_splitk",
 ]
 
 
@@ -110,6 +110,7 @@ def lib():
                                                    i64, i, i, i, i, i, f, p, i, i64, i64, i, i, i,
                                                    p]
         L.vla_fused_add_rms_norm_splitk.argtypes = [p, i, i64, p, p, p, f, i, i, i, p]
+        L.vla_silu_and_mul_splitk.argtypes = [p, i, i64, p, i, i, i, p]
         _lib = L
     return _lib
 

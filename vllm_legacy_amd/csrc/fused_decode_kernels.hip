@@ -269,6 +269,31 @@ __global__ __launch_bounds__(1024) void add_rms_norm_slabs_kernel(
   }
 }
 
+// silu_and_mul whose input [tokens][2 d] arrives as split-K slabs: each half is summed over the
+// slabs (fp32, slab order) and rounded to the model dtype as the GEMM's own reduction would,
+// then out = silu(gate) * up with the activation kernel's arithmetic
+// (csrc/activation_kernels.cu:14-33).  Four outputs per thread.
+template <class S>
+__global__ __launch_bounds__(256) void silu_and_mul_slabs_kernel(
+    const float* __restrict__ slabs, int num_slabs, int64_t slab_stride,
+    typename S::T* __restrict__ out, int d) {
+  const int64_t row = blockIdx.x;
+  const float* src = slabs + row * 2 * d;
+  for (int i = threadIdx.x * 4; i < d; i += blockDim.x * 4) {
+    f32x4 g = *reinterpret_cast<const f32x4*>(src + i);
+    f32x4 u = *reinterpret_cast<const f32x4*>(src + d + i);
+    for (int p = 1; p < num_slabs; ++p) {
+      g += *reinterpret_cast<const f32x4*>(src + (int64_t)p * slab_stride + i);
+      u += *reinterpret_cast<const f32x4*>(src + (int64_t)p * slab_stride + d + i);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float x = rnd<S>(g[e]), y = rnd<S>(u[e]);
+      out[row * d + i + e] = S::from_f32(rnd<S>(x / (1.0f + expf(-x))) * y);
+    }
+  }
+}
+
 }  // namespace
 }  // namespace vla
 
@@ -361,6 +386,20 @@ extern "C" int vla_fused_add_rms_norm_splitk(const float* slabs, int num_slabs, 
                                          dim3(threads), 0, (hipStream_t)stream, slabs, num_slabs, slab_stride,
                                          (typename S::T*)out, (typename S::T*)residual,
                                          (const typename S::T*)weight, epsilon, hidden_size));
+  VLA_HIP_CHECK(hipGetLastError());
+  return VLA_OK;
+}
+
+extern "C" int vla_silu_and_mul_splitk(const float* slabs, int num_slabs, int64_t slab_stride,
+                                       void* out, int num_tokens, int d, int dtype, void* stream) {
+  (void)hipGetLastError();
+  if (num_tokens == 0) return VLA_OK;
+  if (!slabs || !out || num_slabs < 1 || num_tokens < 0 || d <= 0 || d % 4 ||
+      ((uintptr_t)slabs % 16) || (slab_stride % 4))
+    return VLA_ERR_ARG;
+  VLA_BY_DTYPE(dtype, hipLaunchKernelGGL((silu_and_mul_slabs_kernel<S>), dim3(num_tokens), dim3(256),
+                                         0, (hipStream_t)stream, slabs, num_slabs, slab_stride,
+                                         (typename S::T*)out, d));
   VLA_HIP_CHECK(hipGetLastError());
   return VLA_OK;
 }

@@ -69,7 +69,12 @@ class RotaryEmbedding(nn.Module):
 
 class SiluAndMul(nn.Module):
 
-    def forward(self, x: torch.Tensor) -> torch.Tensor:
+    def forward(self, x, dtype: torch.dtype = torch.float16) -> torch.Tensor:
+        if isinstance(x, ops.SplitKSlabs):
+            # the merged gate|up GEMM left its split-K partial sums for this kernel to add up
+            out = torch.empty((x.m, x.n // 2), dtype=dtype, device=x.workspace.device)
+            ops.silu_and_mul_splitk(x, out)
+            return out
         d = x.shape[-1] // 2
         out = torch.empty(x.shape[:-1] + (d, ), dtype=x.dtype, device=x.device)
         ops.silu_and_mul(out, x)

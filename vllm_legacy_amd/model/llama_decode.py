@@ -162,7 +162,9 @@ class LlamaDecodeLayer(nn.Module):
         hidden = self.o_proj(attn_out, defer_reduce=fuse)
         hidden = PendingAllReduce(hidden) if fuse_norm else tensor_model_parallel_all_reduce(hidden, dt)
         hidden, residual = self.post_attention_layernorm(hidden, residual)
-        hidden = self.down_proj(self.act_fn(self.gate_up_proj(hidden)), defer_reduce=fuse)
+        # gate_up is column-parallel: whatever K slices it made are summed by the activation
+        hidden = self.down_proj(self.act_fn(self.gate_up_proj(hidden, defer_reduce=True), dt),
+                                defer_reduce=fuse)
         hidden = PendingAllReduce(hidden) if fuse_norm else tensor_model_parallel_all_reduce(hidden, dt)
         return hidden, residual
 
