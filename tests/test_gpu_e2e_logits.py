@@ -122,7 +122,7 @@ def test_decode_step_logits_match_oracle_pipeline(kv):
         act = O.silu_and_mul(gu, DT)
         h = O.gemm_f16(act, _lin_weights(layer.down_proj))
     h, _ = O.fused_add_rms_norm(h, res, T.bits(model.norm.weight), eps, DT)
-    want = O.from_bits(h, DT).astype(np.float64) @ O.from_bits(T.bits(model.lm_head), DT).astype(np.float64)
+    want = O.from_bits(h, DT).astype(np.float64) @ O.from_bits(T.bits(model.lm_head), DT).astype(np.float64).T
 
     err = np.abs(logits - want).max()
     print(f"kv={kv}: max |logit error| = {err:.3e}, max |logit| = {np.abs(want).max():.3f}")
