@@ -18,6 +18,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from vllm_legacy_amd import _custom_ops as ops  # noqa: E402
 
 SHAPES = {"qkv": (4096, 6144), "o": (4096, 4096), "gate_up": (4096, 28672), "down": (14336, 4096)}
+SHAPES_70B = {"qkv": (8192, 10240), "o": (8192, 8192), "gate_up": (8192, 57344), "down": (28672, 8192)}
 
 
 def main():
@@ -28,11 +29,12 @@ def main():
     ap.add_argument("--check", action="store_true")
     ap.add_argument("--only", default="")
     ap.add_argument("--tp", type=int, default=1, help="per-GPU shapes at this tensor-parallel degree")
+    ap.add_argument("--model", default="8b", choices=["8b", "70b"], help="Llama-3 layer shapes")
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
     g = torch.Generator(device=dev).manual_seed(0)
     res = {}
-    for name, (k, n) in SHAPES.items():
+    for name, (k, n) in (SHAPES if a.model == "8b" else SHAPES_70B).items():
         if a.only and name != a.only:
             continue
         if name in ("qkv", "gate_up"):
