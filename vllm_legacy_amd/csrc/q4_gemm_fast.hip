@@ -508,15 +508,16 @@ struct Q4Shape { int nw, splits, mt; };
 static Q4Shape pick_shape(int m, int n, int k, int group) {
   Q4Shape s;
   // Small batches (one or two 32-row tiles): the kernel streams the weights once, so the grid is
-  // sized for bytes in flight -- 128-column workgroups and K slices until about two workgroups
-  // per CU exist (the slabs of a 32-row batch are small) -- not for MFMA occupancy.
+  // sized for bytes in flight -- 128-column workgroups and K slices until about one workgroup
+  // per CU exists (the slabs of a 32-row batch are small) -- not for MFMA occupancy.
   s.mt = m <= 32 ? 1 : m <= 64 ? 2 : 4;
   const int mtiles = (m + 32 * s.mt - 1) / (32 * s.mt);
   int want;
   if (s.mt < 4) {
     s.nw = 4;
     const int wgs = ((n + 127) / 128) * mtiles;
-    want = (512 + wgs - 1) / wgs;
+    want = (256 + wgs - 1) / wgs;    // qkv (48 column tiles): 4 slices 15.4 / 11.6 / 11.0 us at
+                                     // batch 64 / 32 / 16 against 18.5 / 13.2 / 11.7 with 8
     if (want > 8) want = 8;
     if (want > k / (4 * TK)) want = k / (4 * TK);
   } else if (m <= 256 && k < 4096 && ((n + 127) / 128) * ((m + 31) / 32) >= 192) {
