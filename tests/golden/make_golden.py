@@ -155,6 +155,14 @@ def main():
     ref = build_ref.load_ref()
     assert ref is not None, "reference CPU kernels need AVX-512 on this host"
     torch.manual_seed(0)
+    # OPT-125M on the reference's CPU executor (12 heads of 64, one sequence, bf16, block 16:
+    # vllm/attention/backends/torch_sdpa.py:216-228 -> csrc/cpu/attention.cpp:421-438) and the
+    # per-rank head shape of Llama-3-70B under 8-way tensor parallelism (8 query heads, 1 KV head)
+    attention_case(ref, "attn_bf16_opt125m", torch.bfloat16, [300], 12, 12, 64, 24, False, 8)
+    attention_case(ref, "attn_bf16_llama70b_tp8", torch.bfloat16, [5, 1290, 300], 8, 1, 128, 96,
+                   False, 9)
+    if "--new-only" in sys.argv:
+        return
     attention_case(ref, "attn_f32_gqa", torch.float32, [1, 37, 600], 8, 2, 64, 16, False, 1)
     attention_case(ref, "attn_bf16_alibi", torch.bfloat16, [17, 513, 1030], 4, 4, 128, 16, True,
                    2)

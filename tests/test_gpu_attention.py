@@ -32,7 +32,10 @@ def _check(got: torch.Tensor, want_bits: np.ndarray, dt, fp8):
     np.testing.assert_allclose(g, w, atol=ATOL_FP8 if fp8 else ATOL, rtol=RTOL)
 
 
-NUM_HEADS = [(40, 40), (64, 8), (32, 8)]
+# (40, 40) and (64, 8) are the reference test's; (32, 8) is Llama-3-8B, (12, 12) OPT-125M and
+# (8, 1) one rank of Llama-3-70B under 8-way tensor parallelism (64 / 8 query heads, 8 / 8 KV
+# heads, vllm/model_executor/models/llama.py:103-119)
+NUM_HEADS = [(40, 40), (64, 8), (32, 8), (12, 12), (8, 1)]
 HEAD_SIZES = [64, 80, 96, 112, 128]
 DTYPES = [O.DT_F16, O.DT_BF16]
 
@@ -104,6 +107,39 @@ def test_edge_sequence_lengths(ops, seq_lens, kv_fp8, version):
     _check(out, T.oracle_attention(c, version), O.DT_BF16, kv_fp8)
 
 
+@pytest.mark.parametrize("version", ["v1", "v2"])
+@pytest.mark.parametrize("path", ["mfma", "generic"])
+@pytest.mark.parametrize("kv_fp8", [False, True])
+def test_empty_sequences_give_zero_rows(ops, version, path, kv_fp8):
+    # a padding row of a captured decode batch has seq_len 0: the reference kernels store zeros
+    # for it (V1: exp_sum 0 and zero accumulators, attention_kernels.cu:333-345, :483-495; V2:
+    # the reduce over zero partitions, :637-668), never stale memory
+    seq_lens = [0, 5, 0, 700, 0]
+    c = T.make_attention_case(17, len(seq_lens), (32, 8), 128, 16, O.DT_F16, kv_fp8, False,
+                              max_seq_len=700, num_blocks=96, seq_lens=seq_lens)
+    want = T.oracle_attention(c, version)
+    assert not T.to_f32(want, O.DT_F16)[[0, 2, 4]].any()
+    ops.set_attention_path(1 if path == "generic" else 0)
+    try:
+        out = torch.full_like(c.t_q, float("nan"))
+        kvd = "fp8" if kv_fp8 else "auto"
+        if version == "v1":
+            ops.paged_attention_v1(out, c.t_q, c.t_kc, c.t_vc, c.hkv, c.scale, c.t_bt, c.t_sl,
+                                   c.bs, c.max_seq_len, None, kvd, 1.0)
+        else:
+            S, H, D = out.shape
+            tmp = torch.full((S, H, 2, D), float("nan"), dtype=out.dtype, device="cuda")
+            es = torch.full((S, H, 2), float("nan"), dtype=torch.float32, device="cuda")
+            ml = torch.full_like(es, float("nan"))
+            ops.paged_attention_v2(out, es, ml, tmp, c.t_q, c.t_kc, c.t_vc, c.hkv, c.scale,
+                                   c.t_bt, c.t_sl, c.bs, c.max_seq_len, None, kvd, 1.0)
+        torch.cuda.synchronize()
+    finally:
+        ops.set_attention_path(0)
+    assert not out[[0, 2, 4]].float().cpu().numpy().any()
+    _check(out, want, O.DT_F16, kv_fp8)
+
+
 @pytest.mark.parametrize("kv_fp8", [False, True])
 def test_tail_garbage_is_ignored(ops, kv_fp8):
     # tokens past seq_len inside the last block (and whole unused blocks) may hold NaN/Inf
@@ -156,7 +192,8 @@ def test_strided_query(ops):
     _check(out, T.oracle_attention(c, "v1"), O.DT_F16, False)
 
 
-@pytest.mark.parametrize("name", ["attn_f32_gqa", "attn_bf16_alibi", "attn_f32_d80"])
+@pytest.mark.parametrize("name", ["attn_f32_gqa", "attn_bf16_alibi", "attn_f32_d80",
+                                  "attn_bf16_opt125m", "attn_bf16_llama70b_tp8"])
 def test_against_reference_cpu_kernel_fixtures(ops, golden_dir, name):
     z = np.load(os.path.join(golden_dir, name + ".npz"))
     dt = {"float32": O.DT_F32, "bfloat16": O.DT_BF16}[str(z["dtype"])]

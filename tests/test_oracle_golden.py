@@ -16,7 +16,8 @@ def _load(golden_dir, name):
 
 
 @pytest.mark.parametrize("name,atol", [("attn_f32_gqa", 2e-6), ("attn_f32_d80", 2e-6),
-                                       ("attn_bf16_alibi", 1e-3)])
+                                       ("attn_bf16_alibi", 1e-3), ("attn_bf16_opt125m", 1e-3),
+                                       ("attn_bf16_llama70b_tp8", 1e-3)])
 def test_attention_matches_reference_cpu_kernels(golden_dir, name, atol):
     # The reference CPU kernel divides by the plain sum (csrc/cpu/attention.cpp:62-64) and keeps
     # probabilities in fp32, the GPU kernel (and the oracle) uses 1/(sum+1e-6) and rounds them
@@ -46,6 +47,20 @@ def test_cache_ops_bit_exact(golden_dir, name):
     O.copy_blocks(kc, vc, z["block_mapping"])
     assert np.array_equal(kc, z["key_cache_copied"])
     assert np.array_equal(vc, z["value_cache_copied"])
+
+
+def test_empty_sequence_rows_are_zero():
+    # seq_len 0 (a padding row): zero logits summed, 1 / (0 + 1e-6) times zero accumulators
+    rng = np.random.default_rng(5)
+    q = O.to_bits(rng.standard_normal((3, 4, 64)).astype(np.float32), O.DT_F16)
+    kc = O.to_bits(rng.standard_normal((6, 2, 8, 16, 8)).astype(np.float32), O.DT_F16)
+    vc = O.to_bits(rng.standard_normal((6, 2, 64, 16)).astype(np.float32), O.DT_F16)
+    bt = rng.integers(0, 6, (3, 3)).astype(np.int32)
+    sl = np.array([0, 40, 0], np.int32)
+    o1 = O.paged_attention_v1(q, kc, vc, bt, sl, 0.125, O.DT_F16)
+    o2 = O.paged_attention_v2(q, kc, vc, bt, sl, 0.125, O.DT_F16)[0]
+    for o in (o1, o2):
+        assert not o[[0, 2]].any() and o[1].any()
 
 
 def test_swap_blocks_exact():

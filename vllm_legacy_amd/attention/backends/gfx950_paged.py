@@ -18,6 +18,38 @@ from vllm_legacy_amd.attention.backends.abstract import (AttentionBackend, Atten
 from vllm_legacy_amd.attention.ops.paged_attn import PagedAttention, PagedAttentionMetadata
 
 
+@dataclass
+class BlocksparseParams:
+    """Local + strided block-sparse attention (the role of
+    vllm/attention/backends/blocksparse_attn.py:15-84): a query in sparse block q attends key
+    block k <= q when q - k < local_blocks, or when (k + head * head_sliding_step + 1) %
+    vert_stride == 0."""
+    max_seqlen: int
+    num_heads: int        # query heads of this tensor-parallel rank
+    num_kv_heads: int
+    block_size: int       # tokens per sparse block (not the KV-cache block size)
+    local_blocks: int
+    vert_stride: int
+    homo_head: bool = False         # every head attends the same strided blocks
+    homo_head_group: bool = False   # every query head of a KV group does
+    head_sliding_step: int = 0
+    tp_rank: int = 0
+
+    def __post_init__(self):
+        from vllm_legacy_amd.distributed.parallel_state import (
+            get_tensor_model_parallel_rank, get_tensor_model_parallel_world_size)
+        assert self.block_size > 0 and self.local_blocks >= 0 and self.vert_stride >= 1
+        assert self.num_heads % self.num_kv_heads == 0
+        tp = get_tensor_model_parallel_world_size()
+        self.tp_rank = get_tensor_model_parallel_rank()
+        if self.homo_head:
+            self.head_sliding_step = 0
+        elif self.homo_head_group:   # negative: the offset slides along KV heads
+            self.head_sliding_step = -max(1, int(self.vert_stride / (tp * self.num_kv_heads)))
+        else:
+            self.head_sliding_step = max(1, int(self.vert_stride / (tp * self.num_heads)))
+
+
 class Gfx950PagedAttentionBackend(AttentionBackend):
 
     @staticmethod
@@ -104,8 +136,17 @@ class Gfx950PagedAttentionImpl(AttentionImpl):
                  num_kv_heads: Optional[int] = None, alibi_slopes: Optional[List[float]] = None,
                  sliding_window: Optional[int] = None, kv_cache_dtype: str = "auto",
                  blocksparse_params: Optional[Dict[str, Any]] = None) -> None:
+        self.blocksparse = None
         if blocksparse_params is not None:
-            raise ValueError("the gfx950 paged-attention backend does not support blocksparse attention")
+            # as the reference's block-sparse backend (blocksparse_attn.py:274-287)
+            if alibi_slopes is not None:
+                raise ValueError("Alibi not support for blocksparse flash attention.")
+            if sliding_window is not None:
+                raise ValueError("sliding_window is invalid for blocksparse attention.")
+            bp = dict(blocksparse_params)
+            bp.setdefault("num_heads", num_heads)
+            bp.setdefault("num_kv_heads", num_kv_heads or num_heads)
+            self.blocksparse = BlocksparseParams(**bp)
         # As in the reference's ROCm backend the window only reaches prefix-enabled prompt
         # attention (rocm_flash_attn.py:215-216, :382); a prompt without a cached prefix attends
         # causally to all of itself (:327-363) and decode relies on the caller handing in block
@@ -156,7 +197,16 @@ class Gfx950PagedAttentionImpl(AttentionImpl):
         prefill_meta = attn_metadata.prefill_metadata
         if prefill_meta is not None:
             bt = prefill_meta.block_tables
-            if kv_cache is not None and bt is not None and bt.numel() > 0:
+            if self.blocksparse is not None:
+                # outside the decode hot path: masked attention per prompt through torch (the
+                # reference runs a Triton block-sparse kernel here and, like it, refuses a cached
+                # prefix, blocksparse_attn.py:374-387)
+                assert kv_cache is None or bt is None or bt.numel() == 0, \
+                    "Does not support prefix-enabled attention."
+                output[:n_pre] = _blocksparse_prompt_attention(
+                    query[:n_pre], key[:n_pre], value[:n_pre], prefill_meta.seq_lens, self.scale,
+                    self.num_queries_per_kv, self.blocksparse)
+            elif kv_cache is not None and bt is not None and bt.numel() > 0:
                 # prefix-enabled attention (rocm_flash_attn.py:368-383): the prompt continues
                 # tokens that are already in the cache
                 block_size = value_cache.shape[3]
@@ -192,11 +242,16 @@ class Gfx950PagedAttentionImpl(AttentionImpl):
         decode_meta = attn_metadata.decode_metadata
         if decode_meta is not None:
             assert kv_cache is not None, "decode needs a KV cache"
+            bsp = self.blocksparse
+            sparse = {} if bsp is None else dict(
+                tp_rank=bsp.tp_rank, blocksparse_local_blocks=bsp.local_blocks,
+                blocksparse_vert_stride=bsp.vert_stride, blocksparse_block_size=bsp.block_size,
+                blocksparse_head_sliding_step=bsp.head_sliding_step)
             output[n_pre:] = PagedAttention.forward_decode(
                 query[n_pre:], key_cache, value_cache, decode_meta.block_tables,
                 decode_meta.seq_lens_tensor, decode_meta.max_decode_seq_len, self.kv_cache_dtype,
                 self.num_kv_heads, self.scale, self._alibi(query.device), kv_scale,
-                seq_order=decode_meta.decode_seq_order)
+                seq_order=decode_meta.decode_seq_order, **sparse)
         return output.view(num_tokens, hidden)
 
 
@@ -209,6 +264,33 @@ def _causal_prompt_attention(q, k, v, seq_lens: List[int], scale: float, qpk: in
         ks = k[start:start + n].transpose(0, 1).repeat_interleave(qpk, dim=0)
         vs = v[start:start + n].transpose(0, 1).repeat_interleave(qpk, dim=0)
         o = torch.nn.functional.scaled_dot_product_attention(qs, ks, vs, is_causal=True, scale=scale)
+        out[start:start + n] = o.transpose(0, 1)
+        start += n
+    return out
+
+
+def _blocksparse_prompt_attention(q, k, v, seq_lens: List[int], scale: float, qpk: int,
+                                  bsp: BlocksparseParams) -> torch.Tensor:
+    """Causal local + strided block-sparse attention over each prompt: the dense mask of
+    vllm/attention/ops/blocksparse_attention/utils.py:180-192 applied through torch."""
+    out = torch.empty_like(q)
+    hq = q.shape[1]
+    heads = torch.arange(hq, device=q.device)
+    if bsp.head_sliding_step >= 0:
+        offs = (bsp.tp_rank * hq + heads) * bsp.head_sliding_step + 1
+    else:
+        offs = (bsp.tp_rank * (hq // qpk) + heads // qpk) * (-bsp.head_sliding_step) + 1
+    start = 0
+    for n in seq_lens:
+        pos = torch.arange(n, device=q.device)
+        blk = pos // bsp.block_size
+        qb, kb = blk[:, None], blk[None, :]
+        strided = ((kb[None] + offs[:, None, None]) % bsp.vert_stride) == 0      # [Hq, 1, n]
+        mask = (pos[:, None] >= pos[None, :])[None] & (((qb - kb) < bsp.local_blocks)[None] | strided)
+        qs = q[start:start + n].transpose(0, 1)
+        ks = k[start:start + n].transpose(0, 1).repeat_interleave(qpk, dim=0)
+        vs = v[start:start + n].transpose(0, 1).repeat_interleave(qpk, dim=0)
+        o = torch.nn.functional.scaled_dot_product_attention(qs, ks, vs, attn_mask=mask, scale=scale)
         out[start:start + n] = o.transpose(0, 1)
         start += n
     return out

@@ -99,7 +99,15 @@ __global__ __launch_bounds__(kThreads) void pa_generic_kernel(AttnParams p) {
   const int tid = threadIdx.x;
   const int seq_len = p.seq_lens[seq];
   const int tok_begin = PARTITIONED ? part * kChunk : 0;
-  if (tok_begin >= seq_len) return;  // partition past the end: nothing written (ref :116-119)
+  if (tok_begin >= seq_len) {
+    // partition past the end: nothing written (ref :116-119).  V1 on an empty sequence stores
+    // zeros, as the reference kernel does (exp_sum 0, zero accumulators, :333-345, :483-495).
+    if constexpr (!PARTITIONED) {
+      T* out = reinterpret_cast<T*>(p.out) + ((int64_t)seq * p.num_heads + head) * p.head_size;
+      for (int i = tid; i < p.head_size; i += kThreads) out[i] = S::from_f32(0.f);
+    }
+    return;
+  }
   const int tok_end = PARTITIONED ? min(tok_begin + kChunk, seq_len) : seq_len;
 
   const int D = p.head_size, BS = p.block_size;

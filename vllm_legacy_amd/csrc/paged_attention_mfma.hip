@@ -119,7 +119,16 @@ __global__ __launch_bounds__(kThreads, 2) void pa_mfma_kernel(AttnParams p, int 
 
   const int seq_len = p.seq_lens[seq];
   const int tok_begin = PARTITIONED ? part * VLA_PARTITION_SIZE : 0;
-  if (tok_begin >= seq_len) return;
+  if (tok_begin >= seq_len) {
+    // V1 on an empty sequence (a padding row of a captured batch): the reference kernel ends
+    // with exp_sum 0 and zero accumulators and stores zeros (attention_kernels.cu:333-345,
+    // :483-495).  V2 partitions past the end store nothing (:116-119); its reduce writes zeros.
+    if constexpr (!PARTITIONED) {
+      T* out = reinterpret_cast<T*>(p.out) + ((int64_t)seq * p.num_heads + head_base) * D;
+      for (int idx = threadIdx.x; idx < nheads * D; idx += kThreads) out[idx] = S::from_f32(0.f);
+    }
+    return;
+  }
   const int tok_end = PARTITIONED ? min(tok_begin + VLA_PARTITION_SIZE, seq_len) : seq_len;
   const int last_blk = (tok_end - 1) / kBS;
   const int* bt = p.block_tables + (int64_t)seq * p.max_num_blocks_per_seq;
