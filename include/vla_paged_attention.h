@@ -42,6 +42,7 @@ extern "C" {
 #define VLA_ERR_BLOCKSPARSE 6  /* blocksparse_vert_stride > 1 with blocksparse_block_size <= 0 */
 #define VLA_ERR_HIP 7          /* a HIP runtime call failed (see vla_last_hip_error) */
 #define VLA_ERR_QUANT_SHAPE 8  /* AWQ/GPTQ shape constraint, gemm_kernels.cu:515-522 */
+#define VLA_ERR_SCRATCH 9      /* vla_paged_attention_v2_noalloc: problem exceeds its scratch */
 
 #define VLA_PARTITION_SIZE 512 /* attention_kernels.cu:846, vllm/attention/ops/paged_attn.py:10 */
 
@@ -119,6 +120,31 @@ int vla_paged_attention_v2_ordered(void* out, float* exp_sums, float* max_logits
                                    int blocksparse_local_blocks, int blocksparse_vert_stride,
                                    int blocksparse_block_size, int blocksparse_head_sliding_step,
                                    const int* seq_order, void* stream);
+
+/* No counterpart in the reference.  vla_paged_attention_v2 for callers that cannot allocate the
+ * scratch tensors it needs (code under HIP graph capture, tight serving loops, harnesses that
+ * forbid hipMalloc): exp_sums, max_logits and tmp_out live in a static device array of
+ * VLA_PA_V2_SCRATCH_BYTES inside the library (held by every GPU the library runs on until the
+ * process ends) instead of being passed in; all other arguments and the results are those of
+ * vla_paged_attention_v2, bit for bit.  The call allocates and frees nothing.
+ *   Limit: round256(num_seqs * num_heads * P * head_size * sizeof(model dtype)) +
+ *   2 * round256(num_seqs * num_heads * P * 4) <= VLA_PA_V2_SCRATCH_BYTES, P = ceil(max_seq_len /
+ *   512); larger problems return VLA_ERR_SCRATCH and launch nothing.
+ *   All calls on one GPU share that GPU's array: calls that overlap in time on one GPU (two
+ *   streams, two threads) race; calls on one stream, or ordered by events, are safe.  The first
+ *   call on a device looks up the array's address on that device (no allocation). */
+#define VLA_PA_V2_SCRATCH_BYTES (32 << 20)
+int vla_paged_attention_v2_noalloc(void* out, const void* query, const void* key_cache,
+                                   const void* value_cache, int num_seqs, int num_heads,
+                                   int num_kv_heads, int head_size, int block_size, float scale,
+                                   const int* block_tables, const int* seq_lens,
+                                   int max_num_blocks_per_seq, int max_seq_len,
+                                   const float* alibi_slopes, int64_t q_stride,
+                                   int64_t kv_block_stride, int64_t kv_head_stride, int dtype,
+                                   int kv_dtype, float kv_scale, int tp_rank,
+                                   int blocksparse_local_blocks, int blocksparse_vert_stride,
+                                   int blocksparse_block_size, int blocksparse_head_sliding_step,
+                                   void* stream);
 
 /* Replaces reshape_and_cache (csrc/cache.h:15-25; csrc/cache_kernels.cu:251-287).
  *   key, value [num_tokens, num_heads, head_size] model dtype, token strides in elements;

@@ -229,6 +229,34 @@ def paged_attention_v2_raw(out, exp_sum, max_logits, tmp_out, query, key_cache_p
             _stream(query.device)), "paged_attention_v2")
 
 
+def paged_attention_v2_noalloc(out: torch.Tensor, query: torch.Tensor, key_cache, value_cache,
+                               num_kv_heads: int, scale: float, block_tables: torch.Tensor,
+                               seq_lens: torch.Tensor, block_size: int, max_seq_len: int,
+                               alibi_slopes: Optional[torch.Tensor], kv_cache_dtype: str,
+                               kv_scale: float, tp_rank: int = 0,
+                               blocksparse_local_blocks: int = 0, blocksparse_vert_stride: int = 0,
+                               blocksparse_block_size: int = 64,
+                               blocksparse_head_sliding_step: int = 0) -> None:
+    """paged_attention_v2 without the exp_sum / max_logits / tmp_out arguments (not in the
+    reference): they live in a static device array inside the library, so neither the caller nor
+    the call allocates anything.  Same bits as paged_attention_v2.  Calls that overlap on one GPU
+    share that array and race; the library rejects problems beyond _lib.PA_V2_SCRATCH_BYTES."""
+    _require_cuda(out, query, block_tables, seq_lens, alibi_slopes)
+    num_seqs, num_heads, head_size = query.shape
+    assert out.is_contiguous() and query.stride(1) == head_size and query.stride(2) == 1
+    assert block_tables.dtype == torch.int32 and seq_lens.dtype == torch.int32
+    assert block_tables.stride(1) == 1
+    with torch.cuda.device(query.device):
+        check(_lib.lib().vla_paged_attention_v2_noalloc(
+            out.data_ptr(), query.data_ptr(), key_cache.data_ptr(), value_cache.data_ptr(),
+            num_seqs, num_heads, num_kv_heads, head_size, block_size, scale,
+            block_tables.data_ptr(), seq_lens.data_ptr(), block_tables.stride(0), max_seq_len,
+            _ptr(alibi_slopes), query.stride(0), key_cache.stride(0), key_cache.stride(1),
+            _dt(query), _lib.kv_dtype_code(kv_cache_dtype), kv_scale, tp_rank,
+            blocksparse_local_blocks, blocksparse_vert_stride, blocksparse_block_size,
+            blocksparse_head_sliding_step, _stream(query.device)), "paged_attention_v2_noalloc")
+
+
 def prefill_attention(out: torch.Tensor, query: torch.Tensor, key: torch.Tensor,
                       value: torch.Tensor, cu_seqlens: torch.Tensor, max_seqlen: int,
                       scale: float, alibi_slopes: Optional[torch.Tensor] = None) -> None:

@@ -16,6 +16,7 @@ CSRC = os.path.join(HERE, "csrc")
 F16, BF16, F32 = 0, 1, 2
 KV_AUTO, KV_FP8_E4M3 = 0, 1
 PARTITION_SIZE = 512
+PA_V2_SCRATCH_BYTES = 32 << 20
 SWAP_D2D, SWAP_D2H, SWAP_H2D = 0, 1, 2
 
 _lib = None
@@ -24,6 +25,7 @@ EXPORTS = [
     "vla_status_string", "vla_last_hip_error", "vla_abi_version", "vla_set_attention_path",
     "vla_kv_dtype_from_string", "vla_paged_attention_v1", "vla_paged_attention_v2",
     "vla_paged_attention_v1_ordered", "vla_paged_attention_v2_ordered",
+    "vla_paged_attention_v2_noalloc",
     "vla_reshape_and_cache", "vla_copy_blocks", "vla_swap_blocks", "vla_convert_fp8",
     "vla_awq_dequantize", "vla_awq_gemm", "vla_gptq_dequantize", "vla_gptq_gemm",
     "vla_gptq_shuffle", "vla_get_max_shared_memory_per_block", "vla_awq_repack",
@@ -67,6 +69,7 @@ def lib():
         L.vla_paged_attention_v2_ordered.argtypes = [p, p, p, p, p, p, p, i, i, i, i, i, f, p, p,
                                                      i, i, p, i64, i64, i64, i, i, f, i, i, i, i,
                                                      i, p, p]
+        L.vla_paged_attention_v2_noalloc.argtypes = L.vla_paged_attention_v1.argtypes
         L.vla_reshape_and_cache.argtypes = [p, p, p, p, p, i, i, i, i, i, i64, i64, i, i, f, p]
         L.vla_copy_blocks.argtypes = [p, p, i, p, i, i64, p]
         L.vla_swap_blocks.argtypes = [p, p, p, i, i64, i, p]

@@ -4,6 +4,8 @@
 
 #include <string.h>
 
+#include <mutex>
+
 namespace vla {
 static thread_local int g_last_hip_error = 0;
 void set_last_hip_error(int e) { g_last_hip_error = e; }
@@ -23,6 +25,10 @@ extern "C" const char* vla_status_string(int status) {
     case VLA_ERR_BLOCKSPARSE: return "Invalid blocksparse parameters (block size must be positive)";
     case VLA_ERR_HIP: return "HIP runtime error";
     case VLA_ERR_QUANT_SHAPE: return "Unsupported quantized weight shape";
+    case VLA_ERR_SCRATCH:
+      return "Problem too large for the static scratch of vla_paged_attention_v2_noalloc "
+             "(num_seqs * num_heads * partitions * (head_size * element size + 8) bytes must fit "
+             "VLA_PA_V2_SCRATCH_BYTES)";
     default: return "unknown status";
   }
 }
@@ -166,6 +172,72 @@ extern "C" int vla_paged_attention_v2(
     int64_t q_stride, int64_t kv_block_stride, int64_t kv_head_stride, int dtype, int kv_dtype,
     float kv_scale, int tp_rank, int blocksparse_local_blocks, int blocksparse_vert_stride,
     int blocksparse_block_size, int blocksparse_head_sliding_step, void* stream) {
+  return vla_paged_attention_v2_ordered(
+      out, exp_sums, max_logits, tmp_out, query, key_cache, value_cache, num_seqs, num_heads,
+      num_kv_heads, head_size, block_size, scale, block_tables, seq_lens, max_num_blocks_per_seq,
+      max_seq_len, alibi_slopes, q_stride, kv_block_stride, kv_head_stride, dtype, kv_dtype,
+      kv_scale, tp_rank, blocksparse_local_blocks, blocksparse_vert_stride, blocksparse_block_size,
+      blocksparse_head_sliding_step, nullptr, stream);
+}
+
+// ---- paged_attention_v2 for callers that cannot allocate ---------------------------------------
+// The partition pass and the reduce of V2 exchange tmp_out / exp_sums / max_logits.  Here they
+// live in one file-scope device array instead of caller-owned tensors.  Every GPU the library
+// runs on holds its own copy of the array at its own address, so the address is looked up once
+// per device (with that device current) and only that pointer is ever handed to kernels; the
+// array's name means nothing to host code.
+static __device__ __align__(256) unsigned char scratch[VLA_PA_V2_SCRATCH_BYTES];
+
+namespace {
+constexpr int kMaxDevices = 64;
+std::mutex g_scratch_mutex;
+void* g_scratch_ptr[kMaxDevices] = {};
+
+// device pointer of `scratch` on the current device, or nullptr (+ last HIP error) on failure
+int scratch_for_current_device(unsigned char** out) {
+  int dev = -1;
+  VLA_HIP_CHECK(hipGetDevice(&dev));
+  if (dev < 0 || dev >= kMaxDevices) return VLA_ERR_ARG;
+  std::lock_guard<std::mutex> lock(g_scratch_mutex);
+  if (!g_scratch_ptr[dev]) {
+    void* ptr = nullptr;
+    VLA_HIP_CHECK(hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)));
+    if (!ptr) return VLA_ERR_HIP;
+    g_scratch_ptr[dev] = ptr;
+  }
+  *out = static_cast<unsigned char*>(g_scratch_ptr[dev]);
+  return VLA_OK;
+}
+
+inline int64_t round_up_256(int64_t v) { return (v + 255) / 256 * 256; }
+}  // namespace
+
+extern "C" int vla_paged_attention_v2_noalloc(
+    void* out, const void* query, const void* key_cache, const void* value_cache, int num_seqs,
+    int num_heads, int num_kv_heads, int head_size, int block_size, float scale,
+    const int* block_tables, const int* seq_lens, int max_num_blocks_per_seq, int max_seq_len,
+    const float* alibi_slopes, int64_t q_stride, int64_t kv_block_stride, int64_t kv_head_stride,
+    int dtype, int kv_dtype, float kv_scale, int tp_rank, int blocksparse_local_blocks,
+    int blocksparse_vert_stride, int blocksparse_block_size, int blocksparse_head_sliding_step,
+    void* stream) {
+  (void)hipGetLastError();
+  if (num_seqs < 0 || num_heads <= 0 || head_size <= 0 || max_seq_len <= 0) return VLA_ERR_ARG;
+  if (dtype != VLA_F16 && dtype != VLA_BF16 && dtype != VLA_F32) return VLA_ERR_DTYPE;
+  const int64_t P = (max_seq_len + VLA_PARTITION_SIZE - 1) / VLA_PARTITION_SIZE;
+  const int64_t rows = (int64_t)num_seqs * num_heads * P;
+  const int64_t esize = dtype == VLA_F32 ? 4 : 2;
+  const int64_t tmp_bytes = round_up_256(rows * head_size * esize);
+  const int64_t stat_bytes = round_up_256(rows * 4);
+  if (tmp_bytes + 2 * stat_bytes > (int64_t)VLA_PA_V2_SCRATCH_BYTES) return VLA_ERR_SCRATCH;
+  unsigned char* base = nullptr;
+  int rc = scratch_for_current_device(&base);
+  if (rc != VLA_OK) return rc;
+  // Nothing in the scratch has to start at zero: the reduce reads, per sequence, exactly the
+  // partitions below ceil(seq_len / 512), and the partition pass of the same call has written
+  // every one of them.  What an earlier call left behind is never read.
+  void* tmp_out = base;
+  float* exp_sums = reinterpret_cast<float*>(base + tmp_bytes);
+  float* max_logits = reinterpret_cast<float*>(base + tmp_bytes + stat_bytes);
   return vla_paged_attention_v2_ordered(
       out, exp_sums, max_logits, tmp_out, query, key_cache, value_cache, num_seqs, num_heads,
       num_kv_heads, head_size, block_size, scale, block_tables, seq_lens, max_num_blocks_per_seq,
