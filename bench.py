@@ -7,8 +7,12 @@ Workload (BASELINE.json configs[2], the configuration the metric is quoted on): 
 of Llama-3-8B with AWQ int4 weights and an fp8 KV cache at batch 256, context 4096 -- 32 layers
 of {int4 qkv GEMM, rotary, KV-cache write, paged attention over 4096 cached tokens, int4 o_proj,
 int4 MLP}, lm_head and greedy sampling -- on synthetic random weights and caches.  With N > 1
-(launched by torch.distributed.run) the model is tensor-parallel over N GPUs with RCCL
-all-reduces, the same batch: strong scaling.
+the model is tensor-parallel over N GPUs, one process per GPU, with RCCL all-reduces, the same
+batch: strong scaling.  The N ranks are either started by the caller (`python -m
+torch.distributed.run --nproc-per-node N bench.py --gpus N ...`: RANK / WORLD_SIZE are in the
+environment) or, when `--gpus N` is given to a plain `python bench.py`, by this script itself: the
+parent process touches no GPU, starts torch.distributed.run as a child, relays its output and
+exits with its status.
 
 One JSON line is printed by rank 0.  `value` is batch / step time with everything resident in
 HBM.  `roofline` describes the dominant kernel (paged attention): algorithmic bytes per launch /
@@ -88,6 +92,16 @@ def fill_kv_caches(model, num_blocks, block_size, kv, device):
     return caches
 
 
+def load_profile_record(name):
+    """A small JSON record under profiles/ (written by tools/profile_summary.py from rocprofv3
+    output of a run on an MI355X), or None."""
+    try:
+        with open(os.path.join(ROOT, "profiles", name)) as f:
+            return json.load(f)
+    except (OSError, ValueError):
+        return None
+
+
 def cpu_baseline(args):
     """Reference CPU paged_attention_v1 (bf16, block 16: it has no fp8 and no int4 path,
     csrc/cpu/attention.cpp:241, :429) on a bounded sample of the same attention shape."""
@@ -95,7 +109,9 @@ def cpu_baseline(args):
     from oracle import build_ref
     from oracle import oracle as O
     hq, hkv, d, bs, S = 32, 8, 128, 16, args.seq
-    b = 4
+    # 32 sequences x 4096 tokens of bf16 K and V = 0.5 GiB per call: well past any last-level
+    # cache, so the rate is a DRAM rate (4 sequences, 67 MB, would be partly cache-resident)
+    b = 32
     nb = b * S // bs
     cores = os.cpu_count() or 1
     try:
@@ -129,7 +145,7 @@ def cpu_baseline(args):
     run()
     t0 = time.perf_counter()
     iters = 0
-    while time.perf_counter() - t0 < 10.0:
+    while time.perf_counter() - t0 < 12.0 and iters < 400:     # bounded: <= 12 s, <= 400 calls
         run()
         iters += 1
     dt = (time.perf_counter() - t0) / iters
@@ -140,7 +156,7 @@ def cpu_baseline(args):
         "value": round(tok_s, 3), "unit": "tokens/s", "cores": threads, "kind": kind,
         "sample": (f"attention only: csrc/cpu paged_attention_v1, bf16 KV (the CPU path has no fp8/int4), "
                    f"{b} sequences x {S} tokens, Hq=32 Hkv=8 D=128 block 16, {iters} timed calls, "
-                   f"{dt * 1e3:.1f} ms per layer call = {gbs:.1f} GB/s; tokens/s = {b} / (32 layer calls)"),
+                   f"{dt * 1e3:.1f} ms per layer call = {gbs:.1f} GB/s; tokens/s = {b} / ({layer_calls_per_step} layer calls)"),
     }
 
 
@@ -282,8 +298,35 @@ def select_all_reduce(device, world, rank, hidden, tokens, dtype):
     return rec
 
 
+def launch_ranks(args) -> int:
+    """`python bench.py --gpus N` without a launcher: start N ranks (one process per GPU, as the
+    reference's multiprocessing executor does, vllm/executor/multiproc_gpu_executor.py) with
+    torch.distributed.run as a child process and hand back its exit status.  This process never
+    initialises the GPU (device_count() does not) and replaces nothing that has."""
+    import socket
+    import subprocess
+    rehearsal = os.environ.get("VLA_BENCH_REHEARSAL") == "1"
+    have = torch.cuda.device_count()
+    if have < args.gpus and not rehearsal:
+        print(f"[bench] --gpus {args.gpus} needs {args.gpus} GPUs, this machine shows {have}. "
+              "(VLA_BENCH_REHEARSAL=1 runs the tensor-parallel code path with every rank on GPU 0 "
+              "over Gloo; its numbers mean nothing.)", file=sys.stderr)
+        return 2
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+           f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args))
     if os.environ.get("VLA_BENCH_WATCHDOG"):
         # debugging aid: dump every thread's stack and exit if the run is still going after N s
         import faulthandler
@@ -302,9 +345,19 @@ def main():
         ps.init_distributed_environment(local_rank=local_rank,
                                         backend="gloo" if rehearsal else "nccl")
         ps.initialize_model_parallel(world)
-    assert world == args.gpus or world == 1, "launch with torch.distributed.run for --gpus > 1"
+    if world != args.gpus:
+        raise SystemExit(f"[bench] --gpus {args.gpus} but the launcher started {world} rank(s): the "
+                         "result would be labelled with a GPU count it was not measured on")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    ranks_seen = 1
+    if world > 1:
+        ones = torch.ones(1, dtype=torch.float32, device=device)
+        from vllm_legacy_amd.distributed import communication_op as _co
+        ranks_seen = int(_co.tensor_model_parallel_all_reduce(ones).item())
+        if ranks_seen != args.gpus:
+            raise SystemExit(f"[bench] all-reduce of ones over the group gave {ranks_seen}, "
+                             f"expected {args.gpus}")
 
     from vllm_legacy_amd import _custom_ops as ops
     from vllm_legacy_amd.attention.backends.gfx950_paged import Gfx950PagedAttentionMetadata
@@ -372,6 +425,8 @@ def main():
         if world > 1:
             torch.distributed.barrier()
 
+    graph_note = {"reason": None}
+
     def measure():
         """Capture (when possible), warm up and time args.steps steps; returns (seconds, graph,
         stream)."""
@@ -381,6 +436,10 @@ def main():
         # place the layer stack holds none, and the rehearsal covers the graph path as well
         use_graph = not args.no_graph and (
             not rehearsal or (ar_rec is not None and ar_rec["impl"] == "xgmi"))
+        if args.no_graph:
+            graph_note["reason"] = "--no-graph"
+        elif not use_graph:
+            graph_note["reason"] = "rehearsal on Gloo collectives, which cannot be captured"
         graph = None
         stream = torch.cuda.Stream(device=device)
         with torch.cuda.stream(stream):
@@ -395,9 +454,12 @@ def main():
                     with torch.cuda.graph(graph, stream=stream, capture_error_mode=mode):
                         captured()
                 except Exception as e:  # e.g. a collective that cannot be captured
+                    graph_note["reason"] = (f"capture failed: {type(e).__name__}: "
+                                            f"{str(e).splitlines()[0] if str(e) else ''}")
                     if rank == 0:
-                        print(f"[bench] graph capture failed ({type(e).__name__}: "
-                              f"{str(e).splitlines()[0]}); running eagerly", file=sys.stderr)
+                        print(f"[bench] graph {graph_note['reason']}; running eagerly "
+                              "(hundreds of launches per step: expect a much slower step)",
+                              file=sys.stderr)
                     graph = None
         if use_graph and graph is None:
             # a failed capture leaves its stream unusable: drain the device and move to a fresh one
@@ -441,10 +503,18 @@ def main():
             comm.close()
             ar_rec.update(impl="rccl", note="barrier timeouts during the xgmi run; re-measured on RCCL")
             elapsed, graph, stream = measure()
+    all_reduce_impl = "none"
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
+        from vllm_legacy_amd.distributed import communication_op as _co2
+        from vllm_legacy_amd.distributed import parallel_state as _ps2
+        # what the layer stack's all-reduces ran on in the timed steps (inside the graph when
+        # there is one), and why the ctypes communicator is absent if it is
+        all_reduce_impl = _co2.all_reduce_implementation(device, capturing=graph is not None)
+        if _ps2._TP_RCCL is not None and not _ps2._TP_RCCL.available:
+            all_reduce_impl += f" (rccl-ctypes unavailable: {_ps2._TP_RCCL.reason})"
     ms_per_step = elapsed / args.steps * 1e3
 
     # ---- dominant kernel: paged attention, timed per launch with HIP events on its stream
@@ -487,29 +557,54 @@ def main():
         names = ("qkv_proj", "o_proj", "gate_up_proj", "down_proj")
         with torch.cuda.stream(stream), torch.inference_mode():
             xs = {}
-            flops = 0
+            flops = gemm_algo_bytes = 0
             for nme in names:
                 lin = getattr(layer0, nme)
                 k_in = lin.qweight.shape[0] * (8 if args.quant == "gptq" else 1)
                 n_out = lin.scales.shape[1]
                 xs[nme] = torch.empty((B, k_in), dtype=model.dtype, device=device).uniform_(-1, 1)
                 flops += 2 * B * k_in * n_out
+                groups = lin.scales.shape[0]
+                # int4 weights + zeros (0.5 B) and scales (2 B) per group and column + x in, out
+                gemm_algo_bytes += k_in * n_out // 2 + groups * n_out * 5 // 2 + 2 * B * (k_in + n_out)
             for lyr in model.layers:                      # warm-up: every layer once
                 for nme in names:
                     getattr(lyr, nme)(xs[nme])
             torch.cuda.synchronize()
-            evs = []
-            for lyr in model.layers:
+
+            def all_layers():
+                for lyr in model.layers:
+                    for nme in names:
+                        getattr(lyr, nme)(xs[nme])
+
+            # all layers' GEMMs (each layer its own weights) as one graph: no host launch gaps
+            gemm_graph, gemm_timing = None, "eager launches (graph capture failed): includes launch gaps"
+            try:
+                gemm_graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gemm_graph, stream=stream):
+                    all_layers()
+                gemm_timing = (f"graph replay of {len(model.layers)} layers x 4 GEMMs, every layer "
+                               "its own weights, HIP events around the replay / layers")
+            except Exception:  # noqa: BLE001
+                gemm_graph = None
+                torch.cuda.synchronize()
+            run_gemms = gemm_graph.replay if gemm_graph is not None else all_layers
+            run_gemms()
+            torch.cuda.synchronize()
+            ts = []
+            for _ in range(5):
                 a, b_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 a.record(stream)
-                for nme in names:
-                    getattr(lyr, nme)(xs[nme])
+                run_gemms()
                 b_.record(stream)
-                evs.append((a, b_))
-            torch.cuda.synchronize()
-            # the median layer: eager launches leave host gaps in the slowest ones
-            ts = sorted(a.elapsed_time(b_) for a, b_ in evs)
-            layer_ms = ts[len(ts) // 2]
+                torch.cuda.synchronize()
+                ts.append(a.elapsed_time(b_) / len(model.layers))
+            layer_ms = sorted(ts)[len(ts) // 2]
+        gemm_traffic = None
+        rec = load_profile_record("gemm_traffic.json")
+        if rec is not None and rec.get("workload") == {"m": B, "model": args.model, "quant": "int4",
+                                                       "rank_of": args.rank_of, "world": world}:
+            gemm_traffic = rec.get("bytes_per_layer")
         gemm = {
             "kernel": "q4_gemm_m32_kernel (+ split-K reduce), qkv + o + gate_up + down of one layer",
             "bound": "mfma",
@@ -517,25 +612,33 @@ def main():
             "peak": MFMA_F16_PEAK_TFLOPS,
             "unit": "TFLOP/s",
             "frac": round(flops / (layer_ms * 1e-3) / 1e12 / MFMA_F16_PEAK_TFLOPS, 4),
-            "traffic": None,
+            "traffic": gemm_traffic,
             "algorithmic_flops_per_layer": flops,
+            "algorithmic_bytes_per_layer": gemm_algo_bytes,
             "layer_ms": round(layer_ms, 4),
-            "note": "eager launches, includes launch gaps; tools/gemm_bench.py times the same "
-                    "kernels from a graph",
+            "timing": gemm_timing,
         }
+        krec = load_profile_record("kernel_times.json")
+        if krec is not None and "q4_gemm_layer_us" in krec:
+            gemm["rocprof_layer_us"] = krec["q4_gemm_layer_us"]
+            gemm["rocprof_source"] = krec.get("source")
 
     # HBM bytes per launch from the committed PMC passes, when they were taken on this workload
     traffic = None
+    rec = load_profile_record("attn_traffic.json")
     try:
-        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles",
-                               "attn_traffic.json")) as f:
-            rec = json.load(f)
         w = rec["workload"]
         if (w["batch"], w["seq"], w["kv"], w["num_heads"], w["num_kv_heads"], w["head_size"],
                 w["block_size"]) == (B, S, args.kv, hq, hkv, d, BS):
             traffic = rec["fetch_bytes"] + rec["write_bytes"]
-    except (OSError, KeyError, ValueError):
+    except (TypeError, KeyError, ValueError):
         pass
+    # the same kernel's average duration in the committed rocprofv3 kernel trace of this command
+    rocprof_attn_us = rocprof_src = None
+    krec = load_profile_record("kernel_times.json")
+    if krec is not None and krec.get("workload") == {"batch": B, "seq": S, "kv": args.kv,
+                                                     "model": args.model, "quant": args.quant}:
+        rocprof_attn_us, rocprof_src = krec.get("paged_attention_us"), krec.get("source")
 
     if rank == 0:
         result = {
@@ -560,6 +663,9 @@ def main():
                 "parallelism": (f"tp{world}" if args.rank_of == 1 else
                                 f"compute of one rank of tp{args.rank_of}, no collectives (study)"),
                 "graph": graph is not None,
+                "graph_fallback_reason": None if graph is not None else graph_note["reason"],
+                "ranks_seen": ranks_seen,
+                "all_reduce_impl": all_reduce_impl,
                 "all_reduce": ar_rec,
                 "global_batch": B,
                 "seq_len": S,
@@ -574,9 +680,16 @@ def main():
                 # linear read-only stream measured on an MI355X with tools/exp/read_bw.hip
                 "peak_measured_read": HBM_MEASURED_READ_GBS,
                 "frac_of_measured_read": round(achieved / HBM_MEASURED_READ_GBS, 4),
+                "frac_source": "launch_ms: HIP events around each launch on its stream, this run",
                 "traffic": traffic,
                 "algorithmic_bytes_per_launch": algo_bytes,
                 "launch_ms": round(attn_ms, 4),
+                # rocprofv3 --kernel-trace --stats of this command on the committed build
+                # (profiles/): the profiled process runs every kernel a few percent slower
+                "rocprof_avg_us": rocprof_attn_us,
+                "frac_rocprof": (None if not rocprof_attn_us else
+                                 round(algo_bytes / (rocprof_attn_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)),
+                "rocprof_source": rocprof_src,
                 "attention_share_of_step": round(attn_ms * len(caches) / ms_per_step, 3),
             },
         }

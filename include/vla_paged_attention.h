@@ -354,9 +354,16 @@ int vla_ar_all_reduce_slabs(void* ctx, void* out, const float* slabs, int num_sl
 int vla_ar_all_reduce_add_rms_norm(void* ctx, void* out, const void* in, int num_slabs,
                                    int64_t slab_stride, void* residual, const void* weight,
                                    float epsilon, int rows, int hidden, int dtype, void* stream);
-/* Synchronous.  A barrier wait that saw no peer within its poll limit gives up so that the kernel
- * terminates; *out counts those events on this rank (non-zero: results are invalid). */
+/* A barrier wait that saw no peer within its time bound (10 s of wall clock; VLA_XGMI_WAIT_SECONDS
+ * at vla_ar_create overrides it) gives up so that the kernel terminates.  The event is counted,
+ * the count is sticky, and from the first one on every call on that rank stores NaN in its output
+ * (and, for the fused form, in residual): a lost barrier cannot pass for a sum.  The reference's
+ * custom all-reduce waits without a bound instead (csrc/custom_all_reduce.cuh:180-205).
+ * vla_ar_error_count: synchronous read of the count.  vla_ar_error_count_async: enqueues a 4-byte
+ * copy of it to pinned host memory on `stream`, valid after the caller's next synchronisation --
+ * one per step at a point where the caller synchronises anyway costs nothing. */
 int vla_ar_error_count(void* ctx, int* out);
+int vla_ar_error_count_async(void* ctx, int* host_out, void* stream);
 
 /* ---- fused forms (same results as the separate calls, fewer launches) ----------------------- */
 

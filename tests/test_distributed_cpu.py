@@ -147,3 +147,18 @@ def test_single_process_is_a_no_op():
     assert co.tensor_model_parallel_all_reduce(t) is t
     assert co.tensor_model_parallel_all_gather(t) is t
     assert co.tensor_model_parallel_gather(t) is t
+
+
+def test_rccl_ctypes_communicator_failure_paths_without_gpu():
+    """No GPU here: the communicator must report itself unavailable (never raise) for a single
+    rank and for a library that cannot be loaded, and the all-reduce dispatcher must say what it
+    would use."""
+    from vllm_legacy_amd.distributed import communication_op as co
+    from vllm_legacy_amd.distributed.rccl_communicator import RcclCommunicator, find_rccl_library
+    c = RcclCommunicator(group=None, device=torch.device("cpu"))
+    assert not c.available and c.disabled and c.reason == "single rank"
+    bad = RcclCommunicator(group=None, device=torch.device("cpu"), allow_single_rank=True,
+                           library_path="/nonexistent/librccl.so")
+    assert not bad.available and "OSError" in bad.reason
+    assert find_rccl_library().endswith(("librccl.so", "librccl.so.1"))
+    assert co.all_reduce_implementation(torch.device("cpu"), capturing=True) == "none"

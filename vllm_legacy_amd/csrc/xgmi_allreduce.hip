@@ -25,12 +25,16 @@
 // so a captured graph replays correctly.  Double buffering makes a closing barrier unnecessary:
 // a rank can only start writing a half again two calls later, and it passes the first barrier
 // of the call in between only after every peer has finished reading in the call before.
-// A wait gives up after a bounded number of polls (the kernel always terminates); the count of
-// such events is kept in `err` and makes results invalid.
+// A wait gives up after a bounded TIME (wall clock, default 10 s: a peer that is still repacking
+// weights or capturing a graph is merely late, not gone), so the kernel always terminates.  A
+// timeout can not go unnoticed: it is counted in `err`, which is sticky, and from then on every
+// call on this rank stores NaN in its output instead of a sum (the barrier counts of the ranks
+// may no longer agree, so nothing after a timeout can be trusted).
 // Calls on one communicator must be issued in the same order with the same sizes by all ranks,
 // on one stream per rank.
 #include "vla_common.h"
 
+#include <stdlib.h>
 #include <string.h>
 
 #include <new>
@@ -45,13 +49,15 @@ constexpr int64_t AR_FLAG_OFF = 0;
 constexpr int64_t AR_SEQ_OFF = (int64_t)AR_MAX_BLOCKS * AR_MAX_RANKS * 4;
 constexpr int64_t AR_ERR_OFF = AR_SEQ_OFF + AR_MAX_BLOCKS * 4;
 constexpr int64_t AR_DATA_OFF = 4096;
-constexpr unsigned AR_SPIN_LIMIT = 4u * 1000u * 1000u;   // a few seconds of polling
+constexpr double AR_WAIT_SECONDS = 10.0;                 // default bound of one barrier wait
+constexpr uint32_t AR_POISON = 0x7fff7fffu;              // NaN as two fp16, two bf16 or one fp32
 static_assert(AR_ERR_OFF + 4 <= AR_DATA_OFF, "metadata fits its page");
 
 struct ArParams {
   unsigned char* region[AR_MAX_RANKS];   // every rank's region as mapped here; [rank] is local
   int rank, world;
   int64_t max_bytes;
+  uint64_t wait_ticks;                   // bound of one barrier wait in wall_clock64() ticks
 };
 
 struct ArContext {
@@ -60,30 +66,44 @@ struct ArContext {
   int device;
 };
 
-// All threads of the block have issued the stores the peers are about to read.
-__device__ __forceinline__ void ar_barrier(const ArParams& P, uint32_t count) {
+// All threads of the block have issued the stores the peers are about to read.  Returns true
+// (to every thread of the block) when some peer did not arrive within the time bound.  A rank
+// that has already lost a barrier (`failed`) still signals its peers but no longer waits for
+// them: its output is void anyway, and it should get out of the way quickly.
+__device__ __forceinline__ bool ar_barrier(const ArParams& P, uint32_t count, bool failed) {
   __threadfence_system();
   __syncthreads();
   const int t = threadIdx.x;
+  int timed_out = 0;
   if (t < P.world) {
     uint32_t* theirs = reinterpret_cast<uint32_t*>(P.region[t] + AR_FLAG_OFF) +
                        (blockIdx.x * AR_MAX_RANKS + P.rank);
     __hip_atomic_store(theirs, count, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     uint32_t* mine = reinterpret_cast<uint32_t*>(P.region[P.rank] + AR_FLAG_OFF) +
                      (blockIdx.x * AR_MAX_RANKS + t);
+    const uint64_t t0 = wall_clock64();
     unsigned polls = 0;
     // counts only grow; the signed difference survives a wrap of the counter
-    while ((int32_t)(__hip_atomic_load(mine, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) -
+    while (!failed &&
+           (int32_t)(__hip_atomic_load(mine, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) -
                      count) < 0) {
-      if (++polls > AR_SPIN_LIMIT) {
+      if ((++polls & 1023u) == 0 && wall_clock64() - t0 > P.wait_ticks) {
         atomicAdd(reinterpret_cast<uint32_t*>(P.region[P.rank] + AR_ERR_OFF), 1u);
+        timed_out = 1;
         break;
       }
       __builtin_amdgcn_s_sleep(2);
     }
   }
-  __syncthreads();
+  timed_out = __syncthreads_or(timed_out);
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+  return failed || timed_out != 0;
+}
+
+// Whether an earlier call on this rank lost a barrier (`err` is sticky).
+__device__ __forceinline__ bool ar_failed_before(const ArParams& P) {
+  const uint32_t* err = reinterpret_cast<const uint32_t*>(P.region[P.rank] + AR_ERR_OFF);
+  return __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
 }
 
 template <class S>
@@ -182,7 +202,8 @@ __global__ __launch_bounds__(AR_THREADS) void xgmi_two_shot_kernel(ArParams P, u
     else
       ar_copy(mine + base, in + base, first, len, stride);
   }
-  ar_barrier(P, seq + 1);
+  bool failed = ar_failed_before(P);
+  failed = ar_barrier(P, seq + 1, failed);
 
   // 2. reduce this rank's slice in place
   {
@@ -200,13 +221,17 @@ __global__ __launch_bounds__(AR_THREADS) void xgmi_two_shot_kernel(ArParams P, u
       mine[base + i] = ar_pack<S>(acc);
     }
   }
-  ar_barrier(P, seq + 2);
+  failed = ar_barrier(P, seq + 2, failed);
 
   // 3. gather the slices from their owners
   for (int s = 0; s < P.world; ++s) {
     const int64_t base = s * per, len = min(per, nvec - base);
     const u32x4* src = reinterpret_cast<const u32x4*>(P.region[s] + half);
     ar_copy(out + base, src + base, first, len, stride);
+  }
+  if (failed) {  // a lost barrier: this block's part of the output is not a sum -- make it NaN
+    const u32x4 nan = {AR_POISON, AR_POISON, AR_POISON, AR_POISON};
+    for (int64_t i = first; i < nvec; i += stride) out[i] = nan;
   }
   if (threadIdx.x == 0) __hip_atomic_store(seq_slot, seq + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -258,7 +283,8 @@ __global__ __launch_bounds__(AR_THREADS) void xgmi_two_shot_norm_kernel(
     else
       for (int v = t; v < rv; v += AR_THREADS) mine[r0 + v] = in[r0 + v];
   }
-  ar_barrier(P, PAIR ? seq + 2 : seq + 1);
+  bool failed = ar_failed_before(P);
+  failed = ar_barrier(P, PAIR ? seq + 2 : seq + 1, failed);
 
   // 2. this rank's column range of this block's rows, summed over the ranks in place
   const int cw = rv / P.world, c0 = P.rank * cw;
@@ -276,7 +302,7 @@ __global__ __launch_bounds__(AR_THREADS) void xgmi_two_shot_norm_kernel(
         if (r < P.world) ar_accumulate<S>(acc, w[r]);
       mine[idx] = ar_pack<S>(acc);
     }
-    ar_barrier(P, seq + 2);
+    failed = ar_barrier(P, seq + 2, failed);
   }
 
   // 3. whole rows of the sum from their owners; add the residual, normalise.  A chunk of rows
@@ -353,6 +379,14 @@ __global__ __launch_bounds__(AR_THREADS) void xgmi_two_shot_norm_kernel(
       }
     }
     __syncthreads();                                   // red is reused by the next chunk
+  }
+  if (failed) {  // a lost barrier: the rows this block wrote are not what they claim to be
+    const u32x4 nan = {AR_POISON, AR_POISON, AR_POISON, AR_POISON};
+    for (int row = b; row < rows; row += G)
+      for (int v = t; v < rv; v += AR_THREADS) {
+        out[(int64_t)row * rv + v] = nan;
+        residual[(int64_t)row * rv + v] = nan;
+      }
   }
   if (threadIdx.x == 0) __hip_atomic_store(seq_slot, seq + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -441,10 +475,21 @@ extern "C" int vla_ar_create(void** ctx, int rank, int world, void* const* regio
   c->p.max_bytes = max_bytes;
   c->num_blocks = num_blocks;
   hipError_t e = hipGetDevice(&c->device);
+  int clock_khz = 0;
+  if (e == hipSuccess)
+    e = hipDeviceGetAttribute(&clock_khz, hipDeviceAttributeWallClockRate, c->device);
   if (e != hipSuccess) {
     delete c;
     VLA_HIP_CHECK(e);
   }
+  // VLA_XGMI_WAIT_SECONDS: another bound for one barrier wait (tests of the timeout path)
+  double seconds = AR_WAIT_SECONDS;
+  if (const char* env = getenv("VLA_XGMI_WAIT_SECONDS")) {
+    const double v = atof(env);
+    if (v > 0) seconds = v;
+  }
+  if (clock_khz <= 0) clock_khz = 100000;   // the 100 MHz constant clock of the CDNA parts
+  c->p.wait_ticks = (uint64_t)(seconds * 1000.0 * (double)clock_khz);
   *ctx = c;
   return VLA_OK;
 }
@@ -543,6 +588,16 @@ extern "C" int vla_ar_all_reduce_add_rms_norm(void* ctx, void* out, const void* 
   }
 #undef VLA_AR_NORM
   VLA_HIP_CHECK(hipGetLastError());
+  return VLA_OK;
+}
+
+// Asynchronous form of vla_ar_error_count: enqueues a 4-byte copy of the counter to `host_out`
+// (pinned host memory) on `stream`; the value is there after the caller's next synchronisation.
+extern "C" int vla_ar_error_count_async(void* ctx, int* host_out, void* stream) {
+  ArContext* c = static_cast<ArContext*>(ctx);
+  if (!c || !host_out) return VLA_ERR_ARG;
+  VLA_HIP_CHECK(hipMemcpyAsync(host_out, c->p.region[c->p.rank] + AR_ERR_OFF, 4,
+                               hipMemcpyDeviceToHost, (hipStream_t)stream));
   return VLA_OK;
 }
 

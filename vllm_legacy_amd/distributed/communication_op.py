@@ -14,7 +14,7 @@ from typing import Any, Dict, Optional
 import torch
 import torch.distributed as dist
 
-from .parallel_state import (get_tp_xgmi_all_reduce,
+from .parallel_state import (get_tp_rccl_communicator, get_tp_xgmi_all_reduce,
                              get_tensor_model_parallel_cpu_group,
                              get_tensor_model_parallel_group,
                              get_tensor_model_parallel_rank,
@@ -69,6 +69,34 @@ def tensor_model_parallel_all_reduce_add_rms_norm(pending: PendingAllReduce, res
     return hidden, residual
 
 
+def tensor_model_parallel_poll_all_reduce_error(device) -> None:
+    """Once per step, right before the step's own synchronisation point (reading the sampled
+    tokens): enqueue the peer-memory all-reduce's 4-byte error read.  No-op on RCCL."""
+    if get_tensor_model_parallel_world_size() > 1:
+        xgmi = get_tp_xgmi_all_reduce(device)
+        if xgmi is not None:
+            xgmi.poll_error_async()
+
+
+def tensor_model_parallel_check_all_reduce(device) -> bool:
+    """After that synchronisation point, collectively: False when some rank's peer-memory
+    all-reduce lost a barrier (its outputs of this step are NaN on that rank).  The communicator
+    is then closed on every rank and later steps run on RCCL; the caller repeats the step."""
+    if get_tensor_model_parallel_world_size() == 1:
+        return True
+    xgmi = get_tp_xgmi_all_reduce(device)
+    if xgmi is None:
+        return True
+    bad = torch.tensor([xgmi.polled_error()], dtype=torch.int32)
+    dist.all_reduce(bad, op=dist.ReduceOp.MAX, group=get_tensor_model_parallel_cpu_group())
+    if int(bad.item()) == 0:
+        return True
+    from .parallel_state import set_tp_xgmi_all_reduce
+    set_tp_xgmi_all_reduce(None)
+    xgmi.close()
+    return False
+
+
 def tensor_model_parallel_all_reduce(input_, dtype: torch.dtype = torch.float16) -> torch.Tensor:
     """SUM over the TP group, in place; returns its argument.  Unreduced split-K slabs (see
     tensor_model_parallel_takes_slabs) come back as the finished [m, n] tensor of `dtype` when
@@ -94,8 +122,36 @@ def tensor_model_parallel_all_reduce(input_, dtype: torch.dtype = torch.float16)
         dist.all_reduce(host, group=group)
         input_.copy_(host)
         return input_
+    if input_.is_cuda and input_.is_contiguous():
+        # under graph capture (or always, with VLA_RCCL_CTYPES=always): one ncclAllReduce on the
+        # current stream through the ctypes communicator, as the reference does while capturing
+        # (communication_op.py:85-100 with pynccl.py:109-127)
+        rccl = get_tp_rccl_communicator()
+        if rccl is not None and (_RCCL_CTYPES_ALWAYS or torch.cuda.is_current_stream_capturing()):
+            with rccl.change_state(True, torch.cuda.current_stream(input_.device)):
+                rccl.all_reduce(input_)
+            return input_
     dist.all_reduce(input_, group=group)
     return input_
+
+
+_RCCL_CTYPES_ALWAYS = os.environ.get("VLA_RCCL_CTYPES", "1") == "always"
+
+
+def all_reduce_implementation(device, capturing: bool) -> str:
+    """Which implementation tensor_model_parallel_all_reduce takes for a GPU tensor on `device`:
+    "xgmi" (peer memory), "rccl-ctypes" (ncclAllReduce through ctypes; under capture unless
+    VLA_RCCL_CTYPES=always), "rccl-torch" (torch.distributed), "gloo-staged" (rehearsal) or
+    "none" (one rank).  For result lines and logs."""
+    if get_tensor_model_parallel_world_size() == 1:
+        return "none"
+    if get_tp_xgmi_all_reduce(device) is not None:
+        return "xgmi"
+    if dist.get_backend(get_tensor_model_parallel_group()) == "gloo":
+        return "gloo-staged"
+    if get_tp_rccl_communicator() is not None and (capturing or _RCCL_CTYPES_ALWAYS):
+        return "rccl-ctypes"
+    return "rccl-torch"
 
 
 def tensor_model_parallel_all_gather(input_: torch.Tensor, dim: int = -1) -> torch.Tensor:

@@ -15,7 +15,9 @@ import torch.distributed as dist
 _TP_GROUP: Optional[dist.ProcessGroup] = None
 _TP_CPU_GROUP: Optional[dist.ProcessGroup] = None
 _TP_RANKS = None
+_TP_RCCL = None          # RcclCommunicator (ctypes) of the TP group: the all-reduce under graph capture
 _TP_XGMI = None          # XgmiAllReduce of the TP group, made on first use when enabled
+_TP_XGMI_REFUSED = False  # made on request, failed its self-check: stay on RCCL
 
 
 def init_distributed_environment(world_size: int = -1, rank: int = -1,
@@ -40,7 +42,7 @@ def init_distributed_environment(world_size: int = -1, rank: int = -1,
 
 def initialize_model_parallel(tensor_model_parallel_size: int = 1, backend: Optional[str] = None) -> None:
     """Consecutive ranks form a TP group: [0..tp-1], [tp..2tp-1], ... (parallel_state.py:150-166)."""
-    global _TP_GROUP, _TP_CPU_GROUP, _TP_RANKS
+    global _TP_GROUP, _TP_CPU_GROUP, _TP_RANKS, _TP_RCCL
     assert dist.is_initialized()
     world = dist.get_world_size()
     assert world % tensor_model_parallel_size == 0
@@ -52,6 +54,13 @@ def initialize_model_parallel(tensor_model_parallel_size: int = 1, backend: Opti
         cpu_grp = dist.new_group(ranks, backend="gloo")
         if me in ranks:
             _TP_GROUP, _TP_CPU_GROUP, _TP_RANKS = grp, cpu_grp, ranks
+    # A second, ctypes-level RCCL communicator over the same ranks, as the reference makes one
+    # (parallel_state.py:191-194): torch.distributed's all_reduce cannot be trusted inside a graph
+    # capture, a bare ncclAllReduce on the capturing stream can.  VLA_RCCL_CTYPES=0 leaves it out.
+    if backend == "nccl" and tensor_model_parallel_size > 1 and torch.cuda.is_available() and \
+            os.environ.get("VLA_RCCL_CTYPES", "1") != "0":
+        from .rccl_communicator import RcclCommunicator
+        _TP_RCCL = RcclCommunicator(_TP_CPU_GROUP, torch.device("cuda", torch.cuda.current_device()))
 
 
 def model_parallel_is_initialized() -> bool:
@@ -91,19 +100,40 @@ def get_tensor_model_parallel_src_rank() -> int:
     return _TP_RANKS[0] if _TP_RANKS else 0
 
 
+def get_tp_rccl_communicator():
+    """The ctypes RCCL communicator of the TP group, or None (one rank, a CPU run, library not
+    loadable: `reason` on the object says which)."""
+    return _TP_RCCL if _TP_RCCL is not None and _TP_RCCL.available else None
+
+
 def get_tp_xgmi_all_reduce(device: torch.device):
     """The peer-memory all-reduce of the TP group, or None when RCCL is to be used.  Either
     installed by the caller (set_tp_xgmi_all_reduce, after it has checked and timed it) or, with
     VLA_XGMI_ALLREDUCE=1, made on first use -- which every rank reaches together (the first
     all-reduce of a step); the reference builds its custom all-reduce the same lazy way
     (vllm/distributed/parallel_state.py:170-180 with custom_all_reduce.py:78-130)."""
-    global _TP_XGMI
-    if _TP_XGMI is None and _TP_CPU_GROUP is not None and \
+    global _TP_XGMI, _TP_XGMI_REFUSED
+    if _TP_XGMI is None and not _TP_XGMI_REFUSED and _TP_CPU_GROUP is not None and \
             os.environ.get("VLA_XGMI_ALLREDUCE", "0") == "1":
+        # Set-up allocates, zeroes and synchronises: none of that may happen inside a stream
+        # capture.  A first call made during capture keeps RCCL for the captured graph; the
+        # communicator is built by the first call outside one (warm up before capturing).
+        if torch.cuda.is_current_stream_capturing():
+            return None
         from .xgmi_all_reduce import XgmiAllReduce
-        _TP_XGMI = XgmiAllReduce(_TP_CPU_GROUP, device)
-        if _TP_XGMI.disabled:
-            raise RuntimeError(f"VLA_XGMI_ALLREDUCE=1 but set-up failed: {_TP_XGMI.reason}")
+        comm = XgmiAllReduce(_TP_CPU_GROUP, device)
+        if comm.disabled:
+            raise RuntimeError(f"VLA_XGMI_ALLREDUCE=1 but set-up failed: {comm.reason}")
+        # nobody has tried this communicator on this node: a short bit-exact check against the
+        # sum of the gathered inputs, agreed on by all ranks, before any model output depends on it
+        if comm.self_check():
+            _TP_XGMI = comm
+        else:
+            comm.close()
+            _TP_XGMI_REFUSED = True
+            import warnings
+            warnings.warn("VLA_XGMI_ALLREDUCE=1: the peer-memory all-reduce failed its self-check "
+                          "on this node; staying on RCCL")
     return _TP_XGMI
 
 
@@ -114,7 +144,11 @@ def set_tp_xgmi_all_reduce(comm) -> None:
 
 
 def destroy_model_parallel() -> None:
-    global _TP_GROUP, _TP_CPU_GROUP, _TP_RANKS, _TP_XGMI
+    global _TP_GROUP, _TP_CPU_GROUP, _TP_RANKS, _TP_XGMI, _TP_XGMI_REFUSED, _TP_RCCL
+    _TP_XGMI_REFUSED = False
+    if _TP_RCCL is not None:
+        _TP_RCCL.close()
+        _TP_RCCL = None
     if _TP_XGMI is not None:
         _TP_XGMI.close()
         _TP_XGMI = None

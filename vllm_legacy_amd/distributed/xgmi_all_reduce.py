@@ -36,6 +36,7 @@ class XgmiAllReduce:
         self._ctx = C.c_void_p()
         self._region = C.c_void_p()
         self._peers: List[Optional[int]] = []
+        self._err_host = None
         self.group = group
         self.device = torch.device(device)
         self.max_size = int(max_size)
@@ -172,6 +173,46 @@ class XgmiAllReduce:
         if self.disabled or not self.should_custom_ar(input):
             return None
         return self.all_reduce(input)
+
+    def poll_error_async(self) -> None:
+        """Enqueue a 4-byte copy of the timeout counter to pinned host memory on the current
+        stream.  Meant to be called once per step, right before a point where the caller
+        synchronises anyway (reading the sampled tokens); `polled_error()` then costs nothing."""
+        if self._err_host is None:
+            self._err_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().vla_ar_error_count_async(
+                self._ctx, self._err_host.data_ptr(),
+                torch.cuda.current_stream(self.device).cuda_stream), "ar_error_count_async")
+
+    def polled_error(self) -> int:
+        """The counter as of the last poll_error_async() the device has completed (no
+        synchronisation).  Non-zero: a barrier wait timed out on this rank; every output since is
+        NaN and the communicator must be closed on all ranks."""
+        return 0 if self._err_host is None else int(self._err_host.item())
+
+    def self_check(self, calls: int = 6) -> bool:
+        """Collective.  A few all-reduces of seeded random messages against the fp32 rank-order
+        sum of the inputs gathered over the CPU group, bit for bit, and no barrier timeout; the
+        answer is agreed on by all ranks.  Run before trusting a communicator that nobody has
+        tried on this node."""
+        ok = not self.disabled
+        if ok:
+            g = torch.Generator(device=self.device).manual_seed(4321 + self.rank)
+            for it in range(calls):
+                n = 8 * (1 + it) if it % 2 else min(self.max_size // 2, 256 * 4096)
+                x = torch.empty(n, dtype=torch.float16, device=self.device).uniform_(-1, 1, generator=g)
+                parts = [torch.empty(n, dtype=torch.float16) for _ in range(self.world_size)]
+                dist.all_gather(parts, x.cpu(), group=self.group)
+                want = torch.zeros(n, dtype=torch.float32)
+                for part in parts:
+                    want += part.float()
+                got = self.all_reduce(x)
+                ok = ok and torch.equal(got.cpu(), want.half())
+            ok = ok and self.error_count() == 0
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
+        return int(flag.item()) == 1
 
     def error_count(self) -> int:
         """Barrier waits that timed out on this rank (synchronises the device)."""
