@@ -11,9 +11,13 @@ from tests import pa_testlib as T
 pytestmark = pytest.mark.gpu
 
 
-def test_gptq_experts_take_the_grouped_path():
+@pytest.mark.parametrize("quant", ["gptq", "gptq_act"])
+def test_gptq_experts_take_the_grouped_path(quant):
+    """GPTQ experts, also with activation reordering (desc_act: every expert has its own row
+    permutation, vllm/model_executor/layers/quantization/gptq.py:209-217), run on the grouped
+    launch and give what the reference's per-expert loop gives."""
     from vllm_legacy_amd.model.mixtral_moe import QuantMixtralMoE
-    moe = QuantMixtralMoE(512, 1024, 8, 2, "gptq", 128, "cuda", seed=2)
+    moe = QuantMixtralMoE(512, 1024, 8, 2, quant, 128, "cuda", seed=2)
     for e in moe.experts:
         for lin in (e.w13, e.w2):
             lin.scales.data = (lin.scales.data.float() * 0.3).half()

@@ -638,7 +638,13 @@ def gptq_gemm(a: torch.Tensor, b_q_weight: torch.Tensor, b_gptq_qzeros: torch.Te
     if b_g_idx is not None and b_g_idx.device.type != "meta" and b_g_idx.numel() > 0:
         assert b_g_idx.dtype == torch.int32 and b_g_idx.is_cuda
         gidx = b_g_idx
-    if use_exllama and gidx is None and bit == 4 and k % 64 == 0:
+    group = k // b_gptq_qzeros.shape[0]
+    if use_exllama and bit == 4 and k % 64 == 0 and group % 32 == 0:
+        # exllama layout = the k-packed layout of the MFMA kernel.  An act-ordered checkpoint was
+        # shuffled with its sort permutation (rows grouped), so the activations' columns go
+        # through the same permutation first (q_gemm.cu:224-227 reads a[perm[k]]): one gather.
+        if gidx is not None:
+            x = x.index_select(1, gidx)
         return q4_gemm_packed(x, b_q_weight, b_gptq_qzeros, b_gptq_scales, 1)
     with torch.cuda.device(x.device):
         check(_lib.lib().vla_gptq_gemm(x.data_ptr(), b_q_weight.data_ptr(),

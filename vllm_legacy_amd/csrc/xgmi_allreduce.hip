@@ -230,8 +230,13 @@ __global__ __launch_bounds__(AR_THREADS) void xgmi_two_shot_kernel(ArParams P, u
     ar_copy(out + base, src + base, first, len, stride);
   }
   if (failed) {  // a lost barrier: this block's part of the output is not a sum -- make it NaN
+    // (each thread overwrites exactly the elements it has just gathered: no store of another
+    // thread can land after the poison)
     const u32x4 nan = {AR_POISON, AR_POISON, AR_POISON, AR_POISON};
-    for (int64_t i = first; i < nvec; i += stride) out[i] = nan;
+    for (int s = 0; s < P.world; ++s) {
+      const int64_t base = s * per, len = min(per, nvec - base);
+      for (int64_t i = first; i < len; i += stride) out[base + i] = nan;
+    }
   }
   if (threadIdx.x == 0) __hip_atomic_store(seq_slot, seq + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }

@@ -65,12 +65,14 @@ class QuantLinear(nn.Module):
 
     def __init__(self, in_features: int, out_features: int, quant: str, group_size: int, device,
                  generator: torch.Generator, dtype=torch.float16):
+        """quant: "awq", "gptq", "gptq_act" (GPTQ with activation reordering: desc_act, a random
+        row -> group map as an act-ordered checkpoint carries in g_idx) or "none"."""
         super().__init__()
-        self.quant = quant
+        self.quant = "gptq" if quant == "gptq_act" else quant
         if quant == "awq":
             self.method = AWQLinearMethod(AWQConfig(4, group_size))
-        elif quant == "gptq":
-            self.method = GPTQLinearMethod(GPTQConfig(4, group_size, False))
+        elif quant in ("gptq", "gptq_act"):
+            self.method = GPTQLinearMethod(GPTQConfig(4, group_size, quant == "gptq_act"))
         elif quant == "none":
             self.method = None
         else:
@@ -90,6 +92,9 @@ class QuantLinear(nn.Module):
         s = torch.empty(self.scales.shape, dtype=torch.float32, device=device)
         s.uniform_(0.5, 1.5, generator=generator)
         self.scales.data = (s * (1e-2 * (4096.0 / in_features)**0.5)).to(dtype)
+        if quant == "gptq_act":
+            perm = torch.randperm(in_features, device=device, generator=generator)
+            self.g_idx.data = (perm // group_size).to(torch.int32)
 
     def forward(self, x: torch.Tensor, defer_reduce: bool = False):
         """defer_reduce: the caller feeds the result to a kernel that can sum split-K slabs

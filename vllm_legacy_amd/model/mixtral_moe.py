@@ -77,9 +77,9 @@ class QuantMixtralMoE(nn.Module):
         routing_weights /= routing_weights.sum(dim=-1, keepdim=True)
         return routing_weights, selected_experts
 
-    # experts the grouped launch does not take (GPTQ with activation reordering): below this many
-    # tokens the per-expert gather of forward_routed (host-synchronising) costs more than it
-    # saves and the dense loop is used
+    # experts the grouped launch does not take (group sizes the MFMA kernel has no path for):
+    # below this many tokens the per-expert gather of forward_routed (host-synchronising) costs
+    # more than it saves and the dense loop is used
     ROUTED_MIN_TOKENS = 512
 
     def forward(self, hidden_states: torch.Tensor) -> torch.Tensor:
@@ -91,13 +91,15 @@ class QuantMixtralMoE(nn.Module):
 
     def _grouped_ok(self) -> bool:
         """The grouped launch takes k-packed 4-bit weights: AWQ after its re-layout, GPTQ after the
-        exllama shuffle without activation reordering (g_idx would permute rows per expert)."""
+        exllama shuffle.  With activation reordering (desc_act) every expert's rows were sorted by
+        its own permutation; forward_grouped then gathers each expert's activation columns by that
+        permutation before the launch (what gptq_gemm does for one weight, q_gemm.cu:224-227)."""
         e = self.experts[self.expert_indicies[0]]
         if e.w13.quant == "awq":
             return e.w13.qweight.shape[0] % 64 == 0 and e.w2.qweight.shape[0] % 64 == 0
         if e.w13.quant == "gptq":
             cfg = e.w13.method.quant_config
-            return cfg.weight_bits == 4 and not cfg.desc_act and cfg.group_size % 64 == 0
+            return cfg.weight_bits == 4 and cfg.group_size % 64 == 0
         return False
 
     def _stacked(self):
@@ -108,7 +110,7 @@ class QuantMixtralMoE(nn.Module):
             self._zero_offset = 1 if gptq else 0
 
             def stack(which):
-                pw, pz, sc = [], [], []
+                pw, pz, sc, perms = [], [], [], []
                 for idx in self.expert_indicies:
                     lin = getattr(self.experts[idx], which)
                     if gptq:
@@ -117,6 +119,8 @@ class QuantMixtralMoE(nn.Module):
                                                           dtype=lin.scales.dtype,
                                                           device=lin.scales.device))
                         packed = (lin.qweight.data, lin.qzeros.data)
+                        if lin.method.quant_config.desc_act:
+                            perms.append(lin.g_idx.data.long())     # argsort(g_idx) after first use
                     else:
                         packed = getattr(lin, "_k_packed", None)
                         if packed is None:
@@ -124,7 +128,14 @@ class QuantMixtralMoE(nn.Module):
                     pw.append(packed[0])
                     pz.append(packed[1])
                     sc.append(lin.scales.data)
-                return torch.stack(pw).contiguous(), torch.stack(pz).contiguous(), torch.stack(sc).contiguous()
+                perm = None
+                if perms:
+                    # [local experts + 1, K]: the trailing bucket (rows of other ranks' experts,
+                    # whose products are discarded) keeps its columns where they are
+                    perms.append(torch.arange(perms[0].numel(), device=perms[0].device))
+                    perm = torch.stack(perms).contiguous()
+                return (torch.stack(pw).contiguous(), torch.stack(pz).contiguous(),
+                        torch.stack(sc).contiguous(), perm)
             st = self._stack = (stack("w13"), stack("w2"))
             # local index of every global expert; experts of other ranks share one trailing bucket
             lut = torch.full((self.num_total_experts, ), len(self.expert_indicies), dtype=torch.int64)
@@ -151,8 +162,13 @@ class QuantMixtralMoE(nn.Module):
         xs = hidden_states.index_select(0, token)
         rows = xs.shape[0]
         zo = self._zero_offset
+        row_expert = local[order]
+        if w13[3] is not None:      # act-ordered experts: each row's columns in its expert's order
+            xs = torch.gather(xs, 1, w13[3][row_expert])
         h = ops.q4_gemm_grouped(xs, w13[0], w13[1], w13[2], offsets, zo, rows)
         h = self.experts[self.expert_indicies[0]].act_fn(h)
+        if w2[3] is not None:
+            h = torch.gather(h, 1, w2[3][row_expert])
         y = ops.q4_gemm_grouped(h, w2[0], w2[1], w2[2], offsets, zo, rows)
         y.mul_(routing_weights.reshape(-1)[order].unsqueeze(1))           # fp32 product, fp16 store
         final = torch.zeros_like(hidden_states)
