@@ -130,8 +130,10 @@ def test_decode_step_logits_match_oracle_pipeline(kv, width):
                 wd = O.from_bits(O.convert_fp8(want_c, DT, False), DT)
                 np.testing.assert_allclose(gd, wd, rtol=0.13, atol=3 * 2.0**-9)
             else:
+                # (a rotated key is a difference of two products of the magnitude of k: where it
+                # cancels, the error is an ulp of the products, not of the result)
                 np.testing.assert_allclose(O.from_bits(got, DT), O.from_bits(want_c, DT),
-                                           rtol=2.0**-8, atol=2e-3)
+                                           rtol=2.0**-8, atol=4e-3)
         attn = O.paged_attention_v1(q.reshape(B, hq, d), kc, vc, block_tables, seq_lens, d**-0.5, DT,
                                     kvc, 1.0)
         o = O.gemm_f16(attn.reshape(B, hq * d), _lin_weights(layer.o_proj))

@@ -215,22 +215,31 @@ struct Q4Groups {
   int64_t w_stride, z_stride, s_stride;   // elements between consecutive sets
 };
 
-template <int ZOFF, bool SPLIT, int NW, int MT, bool GROUPED = false, bool G2 = false>
-__global__ __launch_bounds__(64 * NW) void q4_gemm_m32_kernel(
+// KW (small batches): the K range of a workgroup is cut into KW parts, each worked on by its own
+// set of NW waves with its own x tiles in LDS; the parts' accumulators are summed through LDS at
+// the end (a fixed tree, so the result does not depend on timing).  A 32-row step is ~300 cycles
+// of issue work behind a few hundred cycles of load and MFMA-chain latency, so what a small-batch
+// launch lacks is waves per SIMD -- and more K slices across workgroups would pay for them with
+// fp32 slabs in HBM.
+template <int ZOFF, bool SPLIT, int NW, int MT, bool GROUPED = false, bool G2 = false, int KW = 1>
+__global__ __launch_bounds__(64 * NW * KW) void q4_gemm_m32_kernel(
     const _Float16* __restrict__ x, const uint32_t* __restrict__ qw,
     const uint32_t* __restrict__ qz, const _Float16* __restrict__ scales, void* __restrict__ outp,
     int m, int n, int k, int group_size, int k_per_split, Q4Groups gp = Q4Groups{}) {
-  constexpr int THREADS = 64 * NW;
+  constexpr int THREADS = 64 * NW;               // threads of one K part
   constexpr int TMW = 32 * MT;                   // rows per workgroup
   constexpr int X2_TILE_BYTES = TMW * TK * 2;    // one LDS buffer: 16 KiB at MT = 4
   static_assert((TMW * 8) % THREADS == 0, "x staging covers the tile in whole passes");
+  static_assert(KW == 1 || (NW <= 4 && (KW == 2 || KW == 4)), "LDS reduction fits the x buffers");
   constexpr int XCH = (TMW * 8) / THREADS;  // 16-byte chunks of the x tile per thread
   constexpr int XROWS = THREADS / 8;        // rows covered by one pass of the staging threads
-  __shared__ __attribute__((aligned(16))) unsigned char xs[2 * X2_TILE_BYTES];
+  __shared__ __attribute__((aligned(16))) unsigned char xs_all[KW * 2 * X2_TILE_BYTES];
 
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wn = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wn = wave % NW, wk = wave / NW;
+  const int tid = threadIdx.x - wk * THREADS;    // thread index within the K part
+  unsigned char* xs = xs_all + wk * (2 * X2_TILE_BYTES);
   const int h = lane >> 5, c = lane & 31;
   int tile_y = blockIdx.y, row_base = 0, slab_rows = m;
   if constexpr (GROUPED) {
@@ -246,9 +255,10 @@ __global__ __launch_bounds__(64 * NW) void q4_gemm_m32_kernel(
     scales += (int64_t)set * gp.s_stride;
   }
   const int n0 = blockIdx.x * (32 * NW), m0 = tile_y * TMW;
-  const int k_begin = blockIdx.z * k_per_split;
-  const int k_end = min(k, k_begin + k_per_split);
-  const int nsteps = (k_end - k_begin) / TK;
+  const int k_part = k_per_split / KW;           // the host keeps this a whole number of groups
+  const int k_begin = blockIdx.z * k_per_split + wk * k_part;
+  const int k_end = min(k, k_begin + k_part);
+  const int nsteps = k_part / TK;                // the same for every part: barriers stay in step
   if (nsteps <= 0) return;
 
   // ---- x staging: thread -> (row = XROWS i + tid / 8, chunk tid % 8).  Rows past m are clamped
@@ -305,11 +315,18 @@ __global__ __launch_bounds__(64 * NW) void q4_gemm_m32_kernel(
     if constexpr (!G2) load_zs(k0 / group_size, d.zs);
   };
 
-  f32x16 acc[MT];
+  // a single 32-row tile would chain all four MFMAs of a step on one accumulator (each waits for
+  // the one before): odd slices get a second one there
+  constexpr bool DUAL = MT == 1;
+  f32x16 acc[MT], acc_odd[DUAL ? 1 : MT];
 #pragma unroll
   for (int a = 0; a < MT; ++a)
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[a][i] = 0.f;
+  if constexpr (DUAL) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc_odd[0][i] = 0.f;
+  }
 
   const f16x2 sixteenth = {(_Float16)0.0625f, (_Float16)0.0625f};
   // (w & mask) | 0x6400.. as ONE v_and_or_b32: the instruction takes a single scalar or literal
@@ -372,6 +389,14 @@ __global__ __launch_bounds__(64 * NW) void q4_gemm_m32_kernel(
                                                         __builtin_bit_cast(f16x8, bf), acc[a], 0,
                                                         0, 0);
     };
+    auto mma_odd = [&](const u32x4 (&af)[MT], const u32x4& bf) {
+      if constexpr (DUAL)
+        acc_odd[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[0]),
+                                                            __builtin_bit_cast(f16x8, bf),
+                                                            acc_odd[0], 0, 0, 0);
+      else
+        mma(af, bf);
+    };
     // fragments of slice s+1 are requested before the MFMAs of slice s are issued
 #define VLA_SB __builtin_amdgcn_sched_barrier(0)
     u32x4 fa[MT], fb[MT];
@@ -385,7 +410,7 @@ __global__ __launch_bounds__(64 * NW) void q4_gemm_m32_kernel(
     VLA_SB;
     read_a(2, fa);
     VLA_SB;
-    mma(fb, b1);
+    mma_odd(fb, b1);
     b0 = dequant(2);
     VLA_SB;
     read_a(3, fb);
@@ -393,7 +418,7 @@ __global__ __launch_bounds__(64 * NW) void q4_gemm_m32_kernel(
     mma(fa, b0);
     b1 = dequant(3);
     VLA_SB;
-    mma(fb, b1);
+    mma_odd(fb, b1);
 #undef VLA_SB
     if (t + 1 < nsteps) store_x(buf ^ 1, xpark);
     __syncthreads();
@@ -422,6 +447,36 @@ __global__ __launch_bounds__(64 * NW) void q4_gemm_m32_kernel(
   if (t + 1 < nsteps) k_step(t + 1, w1, w0, xb_, xa, za, zb);
   if (t + 2 < nsteps) k_step(t + 2, w2, w1, xa, xb_, zb, za);
 
+  if constexpr (DUAL) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[0][i] += acc_odd[0][i];
+  }
+  // ---- the K parts of the workgroup: parts [stride, 2 stride) hand their sums to parts
+  // [0, stride) through LDS (the x buffers, free after the last step's barrier), stride = KW/2 .. 1
+  if constexpr (KW > 1) {
+    float* red = reinterpret_cast<float*>(xs_all);
+    constexpr int SLOT = NW * MT * 16 * 64;        // floats one part hands over
+#pragma unroll
+    for (int stride = KW / 2; stride >= 1; stride >>= 1) {
+      if (wk >= stride && wk < 2 * stride) {
+        float* dst = red + (wk - stride) * SLOT + wn * (MT * 16 * 64) + lane;
+#pragma unroll
+        for (int a = 0; a < MT; ++a)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) dst[(a * 16 + i) * 64] = acc[a][i];
+      }
+      __syncthreads();
+      if (wk < stride) {
+        const float* src = red + wk * SLOT + wn * (MT * 16 * 64) + lane;
+#pragma unroll
+        for (int a = 0; a < MT; ++a)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) acc[a][i] += src[(a * 16 + i) * 64];
+      }
+      if (stride > 1) __syncthreads();             // the slots are rewritten by the next round
+    }
+    if (wk != 0) return;
+  }
   // ---- epilogue: lane (h, c) holds column ncol, rows (i & 3) + 8 (i >> 2) + 4 h of each 32-row tile
   if (!nok) return;
 #pragma unroll
@@ -503,10 +558,11 @@ using namespace vla;
 //    the slabs and their reduction exceeds what the shorter loop saves (K = 1024, N = 4096:
 //    1 slice 15.3 us, 4 slices 19.2 us).
 // VLA_Q4_TUNE="nw,splits[,mt]" overrides them (kernel studies).
-struct Q4Shape { int nw, splits, mt; };
+struct Q4Shape { int nw, splits, mt, kw; };   // kw: K parts inside a workgroup (small batches)
 
 static Q4Shape pick_shape(int m, int n, int k, int group) {
   Q4Shape s;
+  s.kw = 1;
   // Small batches (one or two 32-row tiles): the kernel streams the weights once, so the grid is
   // sized for bytes in flight -- 128-column workgroups and K slices until about one workgroup
   // per CU exists (the slabs of a 32-row batch are small) -- not for MFMA occupancy.
@@ -514,12 +570,24 @@ static Q4Shape pick_shape(int m, int n, int k, int group) {
   const int mtiles = (m + 32 * s.mt - 1) / (32 * s.mt);
   int want;
   if (s.mt < 4) {
+    // A 32- or 64-row step is a few hundred cycles of issue work per wave behind load, LDS and
+    // MFMA-chain latencies, and the grid alone gives a SIMD about one wave: K parts inside the
+    // workgroup add waves without adding fp32 slabs.  Measured at batch 8 / 32 / 64 (us,
+    // "slices x parts"): gate_up 4096 x 28672 2x1 24.9 / 26.8 / 34.7 -> 1x4 22.3 / 23.7 / 31.0
+    // (and no slabs at all); down 14336 x 4096 8x1 15.9 / 16.6 / 21.6 -> 8x2 14.5 / 15.3 / 19.9;
+    // qkv 4096 x 6144 4x1 10.3 / 11.9 / 15.2 -> 4x2 9.8 / 11.3 / 14.9; o 4096 x 4096 8x1 9.5 /
+    // 11.1 / 14.0 -> 4x2 9.5 / 10.5 / 13.2.  A part shorter than 8 K steps is all prologue.
     s.nw = 4;
     const int wgs = ((n + 127) / 128) * mtiles;
-    want = (256 + wgs - 1) / wgs;    // qkv (48 column tiles): 4 slices 15.4 / 11.6 / 11.0 us at
-                                     // batch 64 / 32 / 16 against 18.5 / 13.2 / 11.7 with 8
-    if (want > 8) want = 8;
-    if (want > k / (4 * TK)) want = k / (4 * TK);
+    if (wgs >= 192) {
+      want = 1;
+      s.kw = 4;
+    } else {
+      s.kw = 2;
+      want = (256 + wgs - 1) / wgs;
+      if (want > 8) want = 8;
+      if (want > k / (s.kw * 8 * TK)) want = k / (s.kw * 8 * TK);
+    }
   } else if (m <= 256 && k < 4096 && ((n + 127) / 128) * ((m + 31) / 32) >= 192) {
     // Short contractions over many columns (the row-parallel layers of a tensor-parallel rank:
     // o_proj 512..2048 x 4096, down_proj 1792..3584 x 4096): a workgroup's loop is a few dozen
@@ -563,18 +631,25 @@ static Q4Shape pick_shape(int m, int n, int k, int group) {
     }
   }
   if (want < 1) want = 1;
+  int kw = s.kw;
   if (const char* e = getenv("VLA_Q4_TUNE")) {
-    int a = 0, b = 0, c = 0;
-    const int got = sscanf(e, "%d,%d,%d", &a, &b, &c);
-    if (got == 3 && (c == 1 || c == 2 || c == 4)) s.mt = c;   // "nw,splits,mt"
+    int a = 0, b = 0, c = 0, d = 0;
+    const int got = sscanf(e, "%d,%d,%d,%d", &a, &b, &c, &d);
+    if (got >= 3 && (c == 1 || c == 2 || c == 4)) s.mt = c;   // "nw,splits,mt[,kw]"
     if (got >= 2 && (a == 4 || (a == 8 && s.mt == 4)) && b >= 1 && b <= 16) {
       s.nw = a;
       want = b;
     }
+    if (got == 4 && (d == 1 || d == 2 || d == 4)) kw = d;
   }
   const int unit = group > TK ? group : TK;  // a split must hold whole groups and whole K steps
   while (want > 1 && (k % (want * unit)) != 0) --want;
   s.splits = want;
+  // K parts inside the workgroup: small row tiles of 128-column workgroups only, whole groups
+  // (pairs of K steps where the per-group constants are fetched per pair) in every part
+  if (s.mt == 4 || s.nw != 4) kw = 1;
+  while (kw > 1 && ((k / want) % (kw * (unit > 2 * TK ? unit : 2 * TK))) != 0) kw >>= 1;
+  s.kw = kw;
   return s;
 }
 
@@ -613,14 +688,24 @@ static int q4_gemm_run(const void* x, const int32_t* qweight, const int32_t* qze
 #define VLA_Q4_ARGS                                                                            \
   (const _Float16*)x, (const uint32_t*)qweight, (const uint32_t*)qzeros, (const _Float16*)scales, \
       dst, m, n, k, group, kps
+#define VLA_Q4_LAUNCH_KW(Z, SP, G2, MT_)                                                       \
+  do {                                                                                         \
+    if (shape.kw == 4)                                                                         \
+      hipLaunchKernelGGL((q4_gemm_m32_kernel<Z, SP, 4, MT_, false, G2, 4>), grid, dim3(1024),  \
+                         0, s, VLA_Q4_ARGS);                                                   \
+    else if (shape.kw == 2)                                                                    \
+      hipLaunchKernelGGL((q4_gemm_m32_kernel<Z, SP, 4, MT_, false, G2, 2>), grid, dim3(512),   \
+                         0, s, VLA_Q4_ARGS);                                                   \
+    else                                                                                       \
+      hipLaunchKernelGGL((q4_gemm_m32_kernel<Z, SP, 4, MT_, false, G2, 1>), grid, dim3(256),   \
+                         0, s, VLA_Q4_ARGS);                                                   \
+  } while (0)
 #define VLA_Q4_LAUNCH_G(Z, SP, G2)                                                             \
   do {                                                                                         \
     if (shape.mt == 1)                                                                         \
-      hipLaunchKernelGGL((q4_gemm_m32_kernel<Z, SP, 4, 1, false, G2>), grid, dim3(256), 0, s,  \
-                         VLA_Q4_ARGS);                                                         \
+      VLA_Q4_LAUNCH_KW(Z, SP, G2, 1);                                                          \
     else if (shape.mt == 2)                                                                    \
-      hipLaunchKernelGGL((q4_gemm_m32_kernel<Z, SP, 4, 2, false, G2>), grid, dim3(256), 0, s,  \
-                         VLA_Q4_ARGS);                                                         \
+      VLA_Q4_LAUNCH_KW(Z, SP, G2, 2);                                                          \
     else if (shape.nw == 8)                                                                    \
       hipLaunchKernelGGL((q4_gemm_m32_kernel<Z, SP, 8, 4, false, G2>), grid, dim3(512), 0, s,  \
                          VLA_Q4_ARGS);                                                         \
@@ -644,6 +729,7 @@ static int q4_gemm_run(const void* x, const int32_t* qweight, const int32_t* qze
   }
 #undef VLA_Q4_LAUNCH
 #undef VLA_Q4_LAUNCH_G
+#undef VLA_Q4_LAUNCH_KW
 #undef VLA_Q4_ARGS
   VLA_HIP_CHECK(hipGetLastError());
   if (splits > 1 && reduce) {
@@ -740,6 +826,15 @@ extern "C" int vla_q4_gemm_grouped(const void* x, const int32_t* qweight, const 
   hipStream_t s = (hipStream_t)stream;
   dim3 grid((n + 127) / 128, num_sets * gp.tiles_per_set, splits);
   const int kps = k / splits;
+  // sets of a few rows (an MoE block at 16-64 decode tokens): two K parts per workgroup (see
+  // pick_shape), whole groups and at least eight K steps in each.  Mixtral-8x7B block from a
+  // graph: 64 tokens 0.412 -> 0.386 ms; at 256 tokens and more the tiles are full enough that
+  // the second part only costs (0.495 -> 0.546 ms), so it stays off there.
+  // VLA_Q4_GROUPED_KW=1 switches it off (kernel studies)
+  const int part_unit = group > 2 * TK ? group : 2 * TK;
+  static const bool kw_enabled = !(getenv("VLA_Q4_GROUPED_KW") && atoi(getenv("VLA_Q4_GROUPED_KW")) == 1);
+  const int kw = (kw_enabled && mt == 2 && total_rows <= 32 * num_sets &&
+                  kps % (2 * part_unit) == 0 && kps / (2 * TK) >= 8) ? 2 : 1;
   void* dst = splits > 1 ? workspace : out;
   if (splits > 1) {
     // rows of sets that got fewer rows than a tile are never written: the sum must not see junk
@@ -752,6 +847,9 @@ extern "C" int vla_q4_gemm_grouped(const void* x, const int32_t* qweight, const 
   do {                                                                                          \
     if (mt == 4)                                                                                \
       hipLaunchKernelGGL((q4_gemm_m32_kernel<Z, SP, 4, 4, true, G2>), grid, dim3(256), 0, s,    \
+                         VLA_Q4G_ARGS);                                                         \
+    else if (kw == 2)                                                                           \
+      hipLaunchKernelGGL((q4_gemm_m32_kernel<Z, SP, 4, 2, true, G2, 2>), grid, dim3(512), 0, s, \
                          VLA_Q4G_ARGS);                                                         \
     else                                                                                        \
       hipLaunchKernelGGL((q4_gemm_m32_kernel<Z, SP, 4, 2, true, G2>), grid, dim3(256), 0, s,    \
