@@ -213,6 +213,7 @@ struct Q4Groups {
   int tiles_per_set;
   int total_rows;              // rows of x / out, the slab pitch of a split product
   int64_t w_stride, z_stride, s_stride;   // elements between consecutive sets
+  int rot_stride;              // > 0: column tile b starts its K walk (b * rot_stride) steps in
 };
 
 // KW (small batches): the K range of a workgroup is cut into KW parts, each worked on by its own
@@ -260,6 +261,15 @@ __global__ __launch_bounds__(64 * NW * KW) void q4_gemm_m32_kernel(
   const int k_end = min(k, k_begin + k_part);
   const int nsteps = k_part / TK;                // the same for every part: barriers stay in step
   if (nsteps <= 0) return;
+  // Optional rotation of the K walk per column tile: logical step t reads physical step
+  // (t + rot) mod nsteps, so that workgroups that start together do not all stream the same
+  // rows of the weight matrix (the same few HBM channels) at the same time.  Even, so that a
+  // two-step quantisation group stays together.
+  const int rot = gp.rot_stride > 0 ? (((int)blockIdx.x * gp.rot_stride) % nsteps) & ~1 : 0;
+  auto phys = [&](int t) {
+    t = min(t, nsteps - 1) + rot;                // past the end: re-read the last step
+    return t >= nsteps ? t - nsteps : t;
+  };
 
   // ---- x staging: thread -> (row = XROWS i + tid / 8, chunk tid % 8).  Rows past m are clamped
   // to the last row: they only feed accumulator rows that are never stored.
@@ -270,7 +280,7 @@ __global__ __launch_bounds__(64 * NW * KW) void q4_gemm_m32_kernel(
     xsrc[i] = x + (int64_t)min(m0 + srow + XROWS * i, m - 1) * k + 8 * schunk;
   struct XSet { u32x4 v[XCH]; };
   auto load_x = [&](int step, XSet& d) {
-    const int k0 = k_begin + min(step, nsteps - 1) * TK;   // past the end: re-read the last step
+    const int k0 = k_begin + phys(step) * TK;
 #pragma unroll
     for (int i = 0; i < XCH; ++i) d.v[i] = *reinterpret_cast<const u32x4*>(xsrc[i] + k0);
   };
@@ -307,8 +317,7 @@ __global__ __launch_bounds__(64 * NW * KW) void q4_gemm_m32_kernel(
     d.s = ssrc[(int64_t)grp * (n >> 1)];
   };
   auto load_w = [&](int step, WStep& d) {
-    step = min(step, nsteps - 1);
-    const int k0 = k_begin + step * TK;
+    const int k0 = k_begin + phys(step) * TK;
     const uint32_t* p = wsrc + (int64_t)(k0 >> 3) * n;
 #pragma unroll
     for (int s = 0; s < 4; ++s) d.w[s] = p[(int64_t)(2 * s) * n];
@@ -337,19 +346,25 @@ __global__ __launch_bounds__(64 * NW * KW) void q4_gemm_m32_kernel(
   constexpr uint32_t kLoMask = 0x000f000fu, kHiMask = 0x00f000f0u;
   auto and_or = [](uint32_t a, uint32_t m, uint32_t c) { return (a & m) | c; };
 
-  // One K step t: issue the loads of x(t+2) into `xnew` and of the weights of step t+3 into
-  // `wnew`, compute step t from `wcur` and LDS buffer t & 1, then park x(t+1) (`xpark`, loaded
-  // a step ago) in the other buffer.  Register sets rotate by NAME (the loop is unrolled by
-  // four), so a register that a load is still writing is never copied.
+  // One K step t: issue the loads of x(t+XAHEAD) into `xnew` and of the weights of step t+3 into
+  // `wnew`, compute step t from `wcur` and LDS buffer t & 1, then park x(t+1) (`xpark`) in the
+  // other buffer.  Register sets rotate by NAME (the loop is unrolled by four), so a register
+  // that a load is still writing is never copied.
+  // Loads complete in program order.  With two x sets (128-row tiles) x(t+1) was requested a
+  // step ago, behind the weights of step t+1: parking it waits for those too, a step before
+  // they are needed -- harmless where a step is ~1000 cycles long.  Small row tiles have short
+  // steps, so they keep four x sets: x(t+1) was requested three steps ago, ahead of every
+  // weight load that step t does not need anyway, and the weights get their full three steps.
+  constexpr int XAHEAD = MT <= 2 ? 4 : 2;
   // G2: zcur holds the constants of step t's group; on even steps znew receives those of the
   // next group (the name the previous group has just released).
   auto k_step = [&](int t, const WStep& wcur, WStep& wnew, XSet& xnew, const XSet& xpark,
                     const ZS& zcur, ZS& znew) {
     const int buf = t & 1;
-    load_x(t + 2, xnew);
+    load_x(t + XAHEAD, xnew);
     load_w(t + 3, wnew);
     if constexpr (G2) {
-      if ((t & 1) == 0) load_zs(group0 + (t >> 1) + 1, znew);
+      if ((t & 1) == 0) load_zs((k_begin + phys(min(t + 2, nsteps - 2)) * TK) / group_size, znew);
     }
     __builtin_amdgcn_sched_barrier(0);               // keep the loads at the top of the step
 
@@ -429,23 +444,43 @@ __global__ __launch_bounds__(64 * NW * KW) void q4_gemm_m32_kernel(
   ZS za, zb;                       // G2: groups group0 + 2i in za, group0 + 2i + 1 in zb
   load_x(0, xa);
   load_x(1, xb_);
-  if constexpr (G2) load_zs(group0, za);
-  load_w(0, w0);
-  load_w(1, w1);
-  load_w(2, w2);
-  store_x(0, xa);
-  __syncthreads();
-
   int t = 0;
-  for (; t + 4 <= nsteps; t += 4) {
-    k_step(t, w0, w3, xa, xb_, za, zb);
-    k_step(t + 1, w1, w0, xb_, xa, za, zb);
-    k_step(t + 2, w2, w1, xa, xb_, zb, za);
-    k_step(t + 3, w3, w2, xb_, xa, zb, za);
+  if constexpr (XAHEAD == 4) {
+    XSet xc, xd;                   // x(j) lives in set j % 4
+    load_x(2, xc);
+    load_x(3, xd);
+    if constexpr (G2) load_zs((k_begin + phys(0) * TK) / group_size, za);
+    load_w(0, w0);
+    load_w(1, w1);
+    load_w(2, w2);
+    store_x(0, xa);
+    __syncthreads();
+    for (; t + 4 <= nsteps; t += 4) {
+      k_step(t, w0, w3, xa, xb_, za, zb);
+      k_step(t + 1, w1, w0, xb_, xc, za, zb);
+      k_step(t + 2, w2, w1, xc, xd, zb, za);
+      k_step(t + 3, w3, w2, xd, xa, zb, za);
+    }
+    if (t < nsteps) k_step(t, w0, w3, xa, xb_, za, zb);
+    if (t + 1 < nsteps) k_step(t + 1, w1, w0, xb_, xc, za, zb);
+    if (t + 2 < nsteps) k_step(t + 2, w2, w1, xc, xd, zb, za);
+  } else {
+    if constexpr (G2) load_zs((k_begin + phys(0) * TK) / group_size, za);
+    load_w(0, w0);
+    load_w(1, w1);
+    load_w(2, w2);
+    store_x(0, xa);
+    __syncthreads();
+    for (; t + 4 <= nsteps; t += 4) {
+      k_step(t, w0, w3, xa, xb_, za, zb);
+      k_step(t + 1, w1, w0, xb_, xa, za, zb);
+      k_step(t + 2, w2, w1, xa, xb_, zb, za);
+      k_step(t + 3, w3, w2, xb_, xa, zb, za);
+    }
+    if (t < nsteps) k_step(t, w0, w3, xa, xb_, za, zb);
+    if (t + 1 < nsteps) k_step(t + 1, w1, w0, xb_, xa, za, zb);
+    if (t + 2 < nsteps) k_step(t + 2, w2, w1, xa, xb_, zb, za);
   }
-  if (t < nsteps) k_step(t, w0, w3, xa, xb_, za, zb);
-  if (t + 1 < nsteps) k_step(t + 1, w1, w0, xb_, xa, za, zb);
-  if (t + 2 < nsteps) k_step(t + 2, w2, w1, xa, xb_, zb, za);
 
   if constexpr (DUAL) {
 #pragma unroll
@@ -685,9 +720,11 @@ static int q4_gemm_run(const void* x, const int32_t* qweight, const int32_t* qze
   dim3 grid((n + tn - 1) / tn, (m + tm - 1) / tm, splits);
   const int kps = k / splits;
   void* dst = splits > 1 ? workspace : out;
+  Q4Groups plain{};
+  if (const char* e = getenv("VLA_Q4_ROT")) plain.rot_stride = atoi(e);   // kernel studies
 #define VLA_Q4_ARGS                                                                            \
   (const _Float16*)x, (const uint32_t*)qweight, (const uint32_t*)qzeros, (const _Float16*)scales, \
-      dst, m, n, k, group, kps
+      dst, m, n, k, group, kps, plain
 #define VLA_Q4_LAUNCH_KW(Z, SP, G2, MT_)                                                       \
   do {                                                                                         \
     if (shape.kw == 4)                                                                         \
@@ -716,7 +753,9 @@ static int q4_gemm_run(const void* x, const int32_t* qweight, const int32_t* qze
 #define VLA_Q4_LAUNCH(Z, SP)                                                                   \
   do {                                                                                         \
     if (!m32)                                                                                  \
-      hipLaunchKernelGGL((q4_gemm_fast_kernel<Z, SP>), grid, dim3(kThreadsG), 0, s, VLA_Q4_ARGS); \
+      hipLaunchKernelGGL((q4_gemm_fast_kernel<Z, SP>), grid, dim3(kThreadsG), 0, s,            \
+                         (const _Float16*)x, (const uint32_t*)qweight, (const uint32_t*)qzeros, \
+                         (const _Float16*)scales, dst, m, n, k, group, kps);                   \
     else if (group == 2 * TK && g2_enabled)                                                    \
       VLA_Q4_LAUNCH_G(Z, SP, true);                                                            \
     else                                                                                       \
@@ -812,7 +851,7 @@ extern "C" int vla_q4_gemm_grouped(const void* x, const int32_t* qweight, const 
   if (splits > 1 && (!workspace || workspace_bytes < need || ((uintptr_t)workspace % 16) ||
                      ((int64_t)total_rows * n) % 4))
     splits = 1;
-  Q4Groups gp;
+  Q4Groups gp{};
   gp.row_offsets = row_offsets;
   // 64-row tiles for decode-sized sets, 128-row tiles once the average set fills them
   // (measured on Mixtral shapes: 256 rows per set 1.25 ms with 64-row tiles, 1.31 with 128-row
