@@ -84,7 +84,45 @@ def record(src, dst, note, workload):
         f.write("\n")
 
 
+def gemm_traffic(fetch_csv, write_csv, dst, note):
+    """HBM bytes of one layer's four int4 GEMM launches at M = 256 from two PMC summaries (this
+    tool's `pmc` output for FETCH_SIZE and for WRITE_SIZE of `tools/gemm_bench.py --m 256`): the
+    unsplit kernel is gate_up, the split-K kernel averages qkv, o and down (equal launch counts)."""
+    import json
+
+    def per_kernel(path, counter):
+        out = {}
+        for r in csv.DictReader(open(path)):
+            if r["Counter"].startswith(counter) and "q4_gemm_m32_kernel" in r["Kernel"]:
+                out[r["Kernel"]] = (float(r["AvgBytes(corrected)"]), int(r["Dispatches"]))
+        return out
+
+    f, w = per_kernel(fetch_csv, "FETCH_SIZE"), per_kernel(write_csv, "WRITE_SIZE")
+    rec = {"comment": "HBM bytes per layer of the int4 GEMMs (qkv + o + gate_up + down, M = 256) from "
+                      "rocprofv3 PMC passes, FETCH_SIZE x 1024 x 2 (gfx950 correction) + WRITE_SIZE x "
+                      "1024; read by bench.py for roofline_gemm.traffic when the workload matches",
+           "command": note,
+           "workload": {"m": 256, "model": "llama3-8b", "quant": "int4", "rank_of": 1, "world": 1},
+           "kernels": {}}
+    total = 0.0
+    for name in f:
+        fb, n = f[name]
+        wb = w.get(name, (0.0, 0))[0]
+        split = "ELb1E" in name.split("q4_gemm_m32_kernel")[1][:12]
+        launches = 3 if split else 1
+        rec["kernels"][name] = {"fetch_bytes": round(fb), "write_bytes": round(wb), "dispatches": n,
+                                "launches_per_layer": launches}
+        total += launches * (fb + wb)
+    rec["bytes_per_layer"] = round(total)
+    with open(dst, "w") as fh:
+        json.dump(rec, fh, indent=1)
+        fh.write("\n")
+
+
 if __name__ == "__main__":
+    if sys.argv[1] == "gemm_traffic":
+        gemm_traffic(*sys.argv[2:6])
+        sys.exit(0)
     mode, src, dst = sys.argv[1:4]
     if mode == "record":
         wl = sys.argv[5:10]

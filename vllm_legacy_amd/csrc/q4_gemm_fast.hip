@@ -213,7 +213,6 @@ struct Q4Groups {
   int tiles_per_set;
   int total_rows;              // rows of x / out, the slab pitch of a split product
   int64_t w_stride, z_stride, s_stride;   // elements between consecutive sets
-  int rot_stride;              // > 0: column tile b starts its K walk (b * rot_stride) steps in
 };
 
 // KW (small batches): the K range of a workgroup is cut into KW parts, each worked on by its own
@@ -261,15 +260,7 @@ __global__ __launch_bounds__(64 * NW * KW) void q4_gemm_m32_kernel(
   const int k_end = min(k, k_begin + k_part);
   const int nsteps = k_part / TK;                // the same for every part: barriers stay in step
   if (nsteps <= 0) return;
-  // Optional rotation of the K walk per column tile: logical step t reads physical step
-  // (t + rot) mod nsteps, so that workgroups that start together do not all stream the same
-  // rows of the weight matrix (the same few HBM channels) at the same time.  Even, so that a
-  // two-step quantisation group stays together.
-  const int rot = gp.rot_stride > 0 ? (((int)blockIdx.x * gp.rot_stride) % nsteps) & ~1 : 0;
-  auto phys = [&](int t) {
-    t = min(t, nsteps - 1) + rot;                // past the end: re-read the last step
-    return t >= nsteps ? t - nsteps : t;
-  };
+  auto phys = [&](int t) { return min(t, nsteps - 1); };   // past the end: re-read the last step
 
   // ---- x staging: thread -> (row = XROWS i + tid / 8, chunk tid % 8).  Rows past m are clamped
   // to the last row: they only feed accumulator rows that are never stored.
@@ -720,11 +711,9 @@ static int q4_gemm_run(const void* x, const int32_t* qweight, const int32_t* qze
   dim3 grid((n + tn - 1) / tn, (m + tm - 1) / tm, splits);
   const int kps = k / splits;
   void* dst = splits > 1 ? workspace : out;
-  Q4Groups plain{};
-  if (const char* e = getenv("VLA_Q4_ROT")) plain.rot_stride = atoi(e);   // kernel studies
 #define VLA_Q4_ARGS                                                                            \
   (const _Float16*)x, (const uint32_t*)qweight, (const uint32_t*)qzeros, (const _Float16*)scales, \
-      dst, m, n, k, group, kps, plain
+      dst, m, n, k, group, kps
 #define VLA_Q4_LAUNCH_KW(Z, SP, G2, MT_)                                                       \
   do {                                                                                         \
     if (shape.kw == 4)                                                                         \
