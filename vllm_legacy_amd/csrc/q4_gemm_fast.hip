@@ -19,6 +19,8 @@
 // Small-N layers are split along K into fp32 slabs that a second kernel sums.
 #include <cstdio>
 #include <cstdlib>
+#include <atomic>
+#include <type_traits>
 
 #include "vla_common.h"
 
@@ -203,6 +205,33 @@ __global__ __launch_bounds__(kThreadsG, 2) void q4_gemm_fast_kernel(
 // MT = 32-row tiles per workgroup: 4 for the batch the kernel is built around; 1 and 2 for small
 // batches, where the work is reading the weights once (HBM-bound) and a 128-row tile would spend
 // MFMA passes and x traffic on rows that do not exist.
+
+// Store a wave's transposed accumulator tiles: acc[a][4 j + e] = out[row0 + 32 a][col0 + 8 j + e]
+// (row0 / col0 already include the lane's c and 4 h); fp32 into slab `row_shift / m` of a split
+// product, fp16 otherwise.  n % 8 == 0, so a quad of columns is inside the matrix or outside it.
+template <bool SPLIT, int MT>
+__device__ __forceinline__ void store_tile(const f32x16 (&acc)[MT], void* __restrict__ outp, int row0,
+                                           int m, int col0, int n, int64_t row_shift) {
+#pragma unroll
+  for (int a = 0; a < MT; ++a) {
+    const int row = row0 + 32 * a;
+    if (row >= m) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int col = col0 + 8 * j;
+      if (col >= n) continue;
+      const int64_t at = (row_shift + row) * n + col;
+      if constexpr (SPLIT) {
+        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(outp) + at) =
+            f32x4{acc[a][4 * j], acc[a][4 * j + 1], acc[a][4 * j + 2], acc[a][4 * j + 3]};
+      } else {
+        const f16x2 lo = {(_Float16)acc[a][4 * j], (_Float16)acc[a][4 * j + 1]};
+        const f16x2 hi = {(_Float16)acc[a][4 * j + 2], (_Float16)acc[a][4 * j + 3]};
+        *reinterpret_cast<u32x2*>(reinterpret_cast<_Float16*>(outp) + at) = u32x2{as_u32(lo), as_u32(hi)};
+      }
+    }
+  }
+}
 
 // GROUPED (several weight sets in one launch, e.g. the experts of an MoE block): x and out hold
 // the row blocks of all sets back to back, gp.row_offsets[e] .. [e + 1] on the device says which
@@ -391,14 +420,14 @@ __global__ __launch_bounds__(64 * NW * KW) void q4_gemm_m32_kernel(
     auto mma = [&](const u32x4 (&af)[MT], const u32x4& bf) {
 #pragma unroll
       for (int a = 0; a < MT; ++a)
-        acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[a]),
-                                                        __builtin_bit_cast(f16x8, bf), acc[a], 0,
+        acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, bf),
+                                                        __builtin_bit_cast(f16x8, af[a]), acc[a], 0,
                                                         0, 0);
     };
     auto mma_odd = [&](const u32x4 (&af)[MT], const u32x4& bf) {
       if constexpr (DUAL)
-        acc_odd[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[0]),
-                                                            __builtin_bit_cast(f16x8, bf),
+        acc_odd[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, bf),
+                                                            __builtin_bit_cast(f16x8, af[0]),
                                                             acc_odd[0], 0, 0, 0);
       else
         mma(af, bf);
@@ -503,19 +532,617 @@ __global__ __launch_bounds__(64 * NW * KW) void q4_gemm_m32_kernel(
     }
     if (wk != 0) return;
   }
-  // ---- epilogue: lane (h, c) holds column ncol, rows (i & 3) + 8 (i >> 2) + 4 h of each 32-row tile
-  if (!nok) return;
+  // ---- epilogue.  The weights are the MFMA's A operand and x its B operand, so the tile comes
+  // out transposed: lane (h, c) holds row 32 a + c of x and, in registers 4 j .. 4 j + 3, the four
+  // adjacent columns 8 j + 4 h .. + 3 of the wave's 32 -- one 8- or 16-byte store per quad instead
+  // of four 2- or 4-byte ones (the store tail of a 128-row tile was a sixth of the kernel).
+  store_tile<SPLIT, MT>(acc, outp, m0 + c, m, n0 + 32 * wn + 4 * h, n,
+                        SPLIT ? (int64_t)blockIdx.z * slab_rows + row_base : (int64_t)row_base);
+}
+
+// ---------------------------------------------------------------------------------------------
+// 128-row tiles with every operand brought in by LDS-DMA (global_load_lds): x, the weight words
+// and the per-group zeros / scales of a K step land in one LDS stage of a ring, nothing is staged
+// through registers, and the only vector-memory wait is one counted s_waitcnt per K step.
+// The tile shape, the dequantisation and the MFMA order are those of q4_gemm_m32_kernel at MT = 4.
+//
+// An LDS-DMA instruction writes 64 lanes x 16 (or 4) bytes contiguously at a wave-uniform LDS
+// address (M0); what each lane fetches is free.  So the images are lane-linear and any swizzle is
+// applied to the SOURCE address:
+//   x    128 rows x 128 bytes, chunk q of row r in slot q ^ ((r >> 1) & 7) (as the register-staged
+//        kernel); one instruction = 8 rows, wave w fills rows [16 w .. ) (NW = 8) or [32 w .. ) (NW = 4).
+//        Every wave reads all of it: it is ordered by the barrier that closes a step.
+//   w    per wave, its own 32 columns: 8 k8-rows x 32 words = one instruction
+//   zs   per wave: the 16 scale-pair words and the 4 zero words of its 32 columns (one 4-byte
+//        instruction; its other lanes repeat the first 16)
+// A wave's weights, zeros and scales are its own: they are ordered by its own vmcnt wait alone, so
+// it reads the words of tile t + 1 into registers BEFORE the barrier that closes step t and starts
+// step t + 1 with its first dequantisation instead of an LDS round trip.
+// Every wave issues PER_TILE instructions per tile, which is what makes one vmcnt literal right.
+// Ring: tile t + D is requested during step t (behind the first MFMAs) into the stage step t - 1
+// has finished reading (every wave passed that step's barrier after its last fragment read
+// returned); at the end of step t a wave waits until at most D - 1 tiles of its own requests are
+// outstanding, then the barrier makes the x of tile t + 1 visible to every wave.
+//
+// One asm statement = the instructions of one tile: M0 is the compiler's register, so it is saved
+// and restored around them once.  x and w: 64-bit scalar base + 32-bit per-lane byte offset (the
+// lane part never changes, the bases walk along K in scalar registers); zs: per-lane 64-bit
+// address (scales and zeros are different tensors), stepped once per quantisation group.
+template <int XP>
+__device__ __forceinline__ void glds_tile(const uint32_t (&xoff)[XP], uint64_t xbase, uint32_t xdst,
+                                          uint32_t woff, uint64_t wbase, uint32_t wdst,
+                                          const void* zsrc, uint32_t zdst) {
+  static_assert(XP == 2 || XP == 4, "x instructions per wave");
+  unsigned keep;
+  if constexpr (XP == 2) {
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %8\n\t"
+        "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %8\n\t"
+        "s_mov_b32 m0, %5\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, %9\n\t"
+        "s_mov_b32 m0, %7\n\ts_nop 0\n\tglobal_load_lds_dword %6, off\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(xoff[0]), "v"(xoff[1]), "s"(xdst), "v"(woff), "s"(wdst), "v"(zsrc), "s"(zdst),
+          "s"(xbase), "s"(wbase)
+        : "memory");
+  } else {
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %5\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %10\n\t"
+        "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %10\n\t"
+        "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %10\n\t"
+        "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, %10\n\t"
+        "s_mov_b32 m0, %7\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %6, %11\n\t"
+        "s_mov_b32 m0, %9\n\ts_nop 0\n\tglobal_load_lds_dword %8, off\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(xoff[0]), "v"(xoff[1]), "v"(xoff[2]), "v"(xoff[3]), "s"(xdst), "v"(woff), "s"(wdst),
+          "v"(zsrc), "s"(zdst), "s"(xbase), "s"(wbase)
+        : "memory");
+  }
+}
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+#ifndef VLA_Q4_ABL
+#define VLA_Q4_ABL 0   // diagnostic builds (wrong results, timing only): 1 no per-step wait and barrier, 2 no dequantisation, 4 no DMA in the loop, 16 no per-step wait, 32 no per-step barrier
+#endif
+template <int NW, int STAGES>
+struct Q4Dma {
+  static constexpr int XB = 128 * 128;          // x tile
+  static constexpr int WB = 1024 * NW;          // 1 KiB of weight words per wave
+  static constexpr int ZB = 256 * NW;           // 256 bytes of scales / zeros per wave
+  static constexpr int STAGE = XB + WB + ZB;
+  static constexpr int BYTES = STAGES * STAGE;
+  static constexpr int XP = 16 / NW;            // x instructions per wave and tile
+  static constexpr int PER_TILE = XP + 2;
+};
+
+template <int ZOFF, bool SPLIT, int NW, int STAGES, int D>
+__global__ __launch_bounds__(64 * NW) void q4_gemm_dma_kernel(
+    const _Float16* __restrict__ x, const uint32_t* __restrict__ qw,
+    const uint32_t* __restrict__ qz, const _Float16* __restrict__ scales, void* __restrict__ outp,
+    int m, int n, int k, int group_size, int k_per_split) {
+  using L = Q4Dma<NW, STAGES>;
+  constexpr int MT = 4;
+  static_assert(NW == 4 || NW == 8, "whole x instructions per wave");
+  static_assert(D >= 1 && STAGES >= D + 1 && STAGES <= 5, "ring depth");
+  static_assert(L::PER_TILE * (D - 1) < 64, "vmcnt is six bits");
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];   // the only LDS object: offset 0
+
+#ifdef VLA_Q4_STAMP
+  const uint64_t st_entry = __builtin_amdgcn_s_memrealtime();
+#endif
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int h = lane >> 5, c = lane & 31;
+  const int n0 = blockIdx.x * (32 * NW), m0 = blockIdx.y * 128;
+  const int k_begin = blockIdx.z * k_per_split;
+  const int nsteps = min(k_per_split, k - k_begin) / TK;
+  if (nsteps <= 0) return;
+  const int wcol0 = n0 + 32 * wave;                        // first column of this wave
+
+  // ---- what this lane fetches (columns past n: clamped to the wave's first or to column 0; the
+  // products they feed are never stored)
+  uint32_t xoff[L::XP];
+#pragma unroll
+  for (int j = 0; j < L::XP; ++j) {
+    const int r = (wave * L::XP + j) * 8 + (lane >> 3);
+    const int q = (lane & 7) ^ ((r >> 1) & 7);
+    xoff[j] = (uint32_t)(min(m0 + r, m - 1) * k + 8 * q) * 2u;       // M K < 2^30 (host check)
+  }
+  uint32_t wlane;
+  {
+    const int r = lane >> 3, col = wcol0 + 4 * (lane & 7);             // k8-row of the step, 4 columns
+    wlane = (uint32_t)(r * n + (col < n ? col : 0)) * 4u;
+  }
+  const unsigned char* zsrc;                               // walks one group per `zs_stride`
+  uint32_t zs_stride;
+  if ((lane & 31) < 16 || (lane & 31) >= 20) {             // scale pairs (lanes 20.. repeat them)
+    const int col = wcol0 + 2 * (lane & 15);
+    zsrc = reinterpret_cast<const unsigned char*>(scales) + (size_t)(col < n ? col : 0) * 2;
+    zs_stride = (uint32_t)n * 2u;
+  } else {                                                 // lanes 16..19 of each half: zero words
+    const int col = wcol0 + 8 * (lane & 3);
+    zsrc = reinterpret_cast<const unsigned char*>(qz) + (size_t)((col < n ? col : 0) >> 3) * 4;
+    zs_stride = (uint32_t)(n >> 3) * 4u;
+  }
+  zsrc += (size_t)(k_begin / group_size) * zs_stride;
+  // scalar bases of the next tile to request; tiles are requested in order 0, 1, 2, ...
+  uint64_t xbase = reinterpret_cast<uint64_t>(x) + (uint64_t)k_begin * 2u;
+  uint64_t wbase = reinterpret_cast<uint64_t>(qw) + (uint64_t)(k_begin >> 3) * (uint64_t)n * 4u;
+  const uint64_t wstep = (uint64_t)(TK / 8) * (uint64_t)n * 4u;
+  const int steps_per_group = group_size / TK;
+  int group_left = steps_per_group - (k_begin / TK) % steps_per_group;   // tiles left in the group
+  const uint32_t xdst0 = (uint32_t)(wave * L::XP * 1024), wdst0 = (uint32_t)(L::XB + wave * 1024),
+                 zdst0 = (uint32_t)(L::XB + L::WB + wave * 256);
+  auto issue = [&](int stage) {
+    const uint32_t base = (uint32_t)(stage * L::STAGE);
+    glds_tile<L::XP>(xoff, xbase, base + xdst0, wlane, wbase, base + wdst0, zsrc, base + zdst0);
+    xbase += TK * 2;
+    wbase += wstep;
+    if (--group_left == 0) {
+      group_left = steps_per_group;
+      zsrc += zs_stride;
+    }
+  };
+
+  // ---- what this lane reads: column c of the wave, k 8h .. 8h + 7 of each 16-deep slice
+  const int woff = L::XB + wave * 1024 + h * 128 + c * 4;  // + 256 s
+  const int soff = L::XB + L::WB + wave * 256 + 4 * (c >> 1), zoff = L::XB + L::WB + wave * 256 + 64 + 4 * (c >> 3);
+  const int zshift = 4 * (c & 7);
+  const uint32_t ssel = (c & 1) ? 0x03020302u : 0x01000100u;
+  const int aoff = c * 128;                                // + a 4096 + ((2 s + h) ^ cs) << 4
+  const int cs = (c >> 1) & 7;
+
+  f32x16 acc[MT];
 #pragma unroll
   for (int a = 0; a < MT; ++a)
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int row = m0 + 32 * a + (i & 3) + 8 * (i >> 2) + 4 * h;
-      if (row >= m) continue;
-      if constexpr (SPLIT)
-        reinterpret_cast<float*>(outp)[((int64_t)blockIdx.z * slab_rows + row_base + row) * n + ncol] = acc[a][i];
-      else
-        reinterpret_cast<_Float16*>(outp)[(int64_t)(row_base + row) * n + ncol] = (_Float16)acc[a][i];
+    for (int i = 0; i < 16; ++i) acc[a][i] = 0.f;
+
+  const f16x2 sixteenth = {(_Float16)0.0625f, (_Float16)0.0625f};
+  uint32_t c1024 = 0x64006400u;
+  asm volatile("" : "+v"(c1024));
+  constexpr uint32_t kLoMask = 0x000f000fu, kHiMask = 0x00f000f0u;
+  auto and_or = [](uint32_t a, uint32_t msk, uint32_t cc) { return (a & msk) | cc; };
+
+  struct Words { uint32_t w[4], sw, zw; };                 // a tile's raw words of this lane
+  struct Consts { f16x2 zc1, zc2, sc2; };
+  auto load_words = [&](const unsigned char* st, Words& d) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) d.w[s] = *reinterpret_cast<const uint32_t*>(st + woff + 256 * s);
+    d.sw = *reinterpret_cast<const uint32_t*>(st + soff);
+    d.zw = *reinterpret_cast<const uint32_t*>(st + zoff);
+  };
+  auto make_consts = [&](const Words& d) {
+    const uint32_t z = ((d.zw >> zshift) & 15u) + ZOFF;
+    Consts r;
+    r.zc1 = as_h2((z * 0x00010001u) | 0xE400E400u);
+    r.zc2 = as_h2((z * 0x00100010u) | 0xD400D400u);
+    r.sc2 = as_h2(__builtin_amdgcn_perm(d.sw, d.sw, ssel));
+    return r;
+  };
+  auto read_a = [&](const unsigned char* st, int s, u32x4 (&af)[MT]) {
+#pragma unroll
+    for (int a = 0; a < MT; ++a)
+      af[a] = *reinterpret_cast<const u32x4*>(st + aoff + a * 4096 + (((2 * s + h) ^ cs) << 4));
+  };
+  auto dequant = [&](uint32_t wv, const Consts& q) {
+    const uint32_t w8 = wv >> 8;
+    if constexpr ((VLA_Q4_ABL & 2) != 0) return u32x4{wv & 0x3bff3bffu, w8 & 0x3bff3bffu, wv & 0x37ff37ffu, w8 & 0x33ff33ffu};
+    const f16x2 d0 = as_h2(and_or(wv, kLoMask, c1024)) + q.zc1;
+    const f16x2 d1 = __builtin_elementwise_fma(as_h2(and_or(wv, kHiMask, c1024)), sixteenth, q.zc2);
+    const f16x2 d2 = as_h2(and_or(w8, kLoMask, c1024)) + q.zc1;
+    const f16x2 d3 = __builtin_elementwise_fma(as_h2(and_or(w8, kHiMask, c1024)), sixteenth, q.zc2);
+    u32x4 bf;
+    bf[0] = as_u32(d0 * q.sc2);
+    bf[1] = as_u32(d1 * q.sc2);
+    bf[2] = as_u32(d2 * q.sc2);
+    bf[3] = as_u32(d3 * q.sc2);
+    return bf;
+  };
+  auto mma = [&](const u32x4 (&af)[MT], const u32x4& bf) {
+#pragma unroll
+    for (int rep = 0; rep < (((VLA_Q4_ABL & 64) != 0) ? 2 : 1); ++rep)
+#pragma unroll
+    for (int a = 0; a < MT; ++a)
+      acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, bf),
+                                                      __builtin_bit_cast(f16x8, af[a]), acc[a], 0, 0,
+                                                      0);
+  };
+#define VLA_SB __builtin_amdgcn_sched_barrier(0)
+  Words wd;                                                // words of the tile about to be computed
+  auto step = [&](auto stage_c, int t) {
+    constexpr int ST = decltype(stage_c)::value;
+    const unsigned char* st = lds + ST * L::STAGE;
+    const unsigned char* stn = lds + ((ST + 1) % STAGES) * L::STAGE;
+    const Consts q = make_consts(wd);
+    u32x4 fa[MT], fb[MT];
+    read_a(st, 0, fa);
+    u32x4 b0 = dequant(wd.w[0], q);
+    VLA_SB;
+    read_a(st, 1, fb);
+    VLA_SB;
+    mma(fa, b0);
+    u32x4 b1 = dequant(wd.w[1], q);
+    VLA_SB;
+    if constexpr ((VLA_Q4_ABL & 4) == 0) {                 // behind the first MFMAs, not before them
+      if (t + D < nsteps) issue((ST + D) % STAGES);
     }
+    VLA_SB;
+    read_a(st, 2, fa);
+    VLA_SB;
+    mma(fb, b1);
+    b0 = dequant(wd.w[2], q);
+    VLA_SB;
+    read_a(st, 3, fb);
+    VLA_SB;
+    mma(fa, b0);
+    b1 = dequant(wd.w[3], q);
+    VLA_SB;
+    mma(fb, b1);
+    VLA_SB;
+    if constexpr ((VLA_Q4_ABL & 1) == 0) {
+      if constexpr ((VLA_Q4_ABL & 16) == 0) {
+        if (t + D < nsteps) wait_vmcnt<L::PER_TILE * (D - 1)>(); else wait_vmcnt<0>();
+      } else {
+        if (t + 1 >= nsteps) wait_vmcnt<0>();
+      }
+      if (t + 1 < nsteps) load_words(stn, wd);             // this wave's own bytes: no barrier needed
+      if constexpr ((VLA_Q4_ABL & 32) == 0) __builtin_amdgcn_s_barrier();
+    } else {
+      if (t + 1 >= nsteps) wait_vmcnt<0>();
+      if (t + 1 < nsteps) load_words(stn, wd);
+    }
+    asm volatile("" ::: "memory");
+  };
+#undef VLA_SB
+
+  // ---- prologue: tiles 0 .. D - 1 requested, tile 0 landed
+#pragma unroll
+  for (int j = 0; j < D; ++j)
+    if (j < nsteps) issue(j);
+  if (D <= nsteps) wait_vmcnt<L::PER_TILE * (D - 1)>(); else wait_vmcnt<0>();
+  load_words(lds, wd);
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+#ifdef VLA_Q4_STAMP   // diagnostic build: shader clock of the K loop (cycles per 100 MHz tick)
+  const uint64_t st_c0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1 % STAGES>;
+  using I2 = std::integral_constant<int, 2 % STAGES>;
+  using I3 = std::integral_constant<int, 3 % STAGES>;
+  using I4 = std::integral_constant<int, 4 % STAGES>;
+  {
+    int t = 0;
+    for (; t + STAGES <= nsteps; t += STAGES) {
+      step(I0{}, t);
+      step(I1{}, t + 1);
+      if constexpr (STAGES >= 3) step(I2{}, t + 2);
+      if constexpr (STAGES >= 4) step(I3{}, t + 3);
+      if constexpr (STAGES >= 5) step(I4{}, t + 4);
+    }
+    if (t < nsteps) step(I0{}, t);
+    if (t + 1 < nsteps) step(I1{}, t + 1);
+    if constexpr (STAGES >= 4) {
+      if (t + 2 < nsteps) step(I2{}, t + 2);
+    }
+    if constexpr (STAGES >= 5) {
+      if (t + 3 < nsteps) step(I3{}, t + 3);
+    }
+  }
+#ifdef VLA_Q4_STAMP
+  const uint64_t st_c1 = __builtin_amdgcn_s_memtime(), st_r1 = __builtin_amdgcn_s_memrealtime();
+#endif
+
+  store_tile<SPLIT, MT>(acc, outp, m0 + c, m, wcol0 + 4 * h, n,
+                        SPLIT ? (int64_t)blockIdx.z * m : (int64_t)0);
+#ifdef VLA_Q4_STAMP
+  {
+    wait_vmcnt<0>();
+    const uint64_t st_end = __builtin_amdgcn_s_memrealtime();
+    if ((threadIdx.x == 0 || threadIdx.x == 64 * NW - 64) && blockIdx.z == 0 && ((blockIdx.x + 3 * blockIdx.y) % 37) == 0)
+      printf("stamp wg %d,%d wave %d steps %d entry %llu loop0 +%llu loop1 +%llu end +%llu MHz %.0f cyc/step %.0f\n",
+             blockIdx.x, blockIdx.y, wave, nsteps, (unsigned long long)(st_entry % 100000000ull),
+             (unsigned long long)(st_r0 - st_entry), (unsigned long long)(st_r1 - st_entry),
+             (unsigned long long)(st_end - st_entry),
+             100.0 * (double)(st_c1 - st_c0) / (double)(st_r1 - st_r0), (double)(st_c1 - st_c0) / nsteps);
+  }
+#endif
+}
+
+// ---------------------------------------------------------------------------------------------
+// The LDS-DMA kernel with 128 x 64 wave tiles: 8 waves = 4 column waves x 2 K parts.  A wave owns
+// 64 columns (two 32-column groups, 128 accumulator registers) over HALF of the workgroup's K
+// range; the two parts' sums meet through LDS at the end.  Per K step a wave now issues 32 MFMAs
+// behind the same 16 fragment reads, one barrier and one round of requests that served 16 before:
+// a step of the 128 x 32 tile spends ~600 cycles per SIMD on everything that is not an MFMA (counter
+// passes: 143 other instructions per 16 MFMAs, one issue slot each), and measured with the MFMAs
+// of a step simply issued twice the matrix pipe's share rose from 0.62 to 0.79.
+// The workgroup tile (128 x 256), the grid and the K slicing across workgroups stay as they are.
+// Each K part has its own x ring (its 4 waves fill and read it); the barrier is the workgroup's.
+__device__ __forceinline__ void glds_tile2(const uint32_t (&xoff)[4], uint64_t xbase, uint32_t xdst,
+                                           const uint32_t (&woff)[2], uint64_t wbase, uint32_t wdst,
+                                           const void* zsrc, uint32_t zdst) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %5\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %11\n\t"
+      "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %11\n\t"
+      "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %11\n\t"
+      "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, %11\n\t"
+      "s_mov_b32 m0, %8\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %6, %12\n\t"
+      "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %7, %12\n\t"
+      "s_mov_b32 m0, %10\n\ts_nop 0\n\tglobal_load_lds_dword %9, off\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(xoff[0]), "v"(xoff[1]), "v"(xoff[2]), "v"(xoff[3]), "s"(xdst), "v"(woff[0]), "v"(woff[1]),
+        "s"(wdst), "v"(zsrc), "s"(zdst), "s"(xbase), "s"(wbase)
+      : "memory");
+}
+
+template <int STAGES>
+struct Q4Dma2 {
+  static constexpr int XB = 128 * 128;          // x tile of one K part
+  static constexpr int WB = 4 * 2048;           // 2 KiB of weight words per wave
+  static constexpr int ZB = 4 * 256;            // 256 bytes of scales / zeros per wave
+  static constexpr int PART = XB + WB + ZB;     // one K part's share of a stage
+  static constexpr int STAGE = 2 * PART;
+  static constexpr int BYTES = STAGES * STAGE;
+  static constexpr int PER_TILE = 7;            // 4 x + 2 w + 1 zeros / scales
+  static_assert(BYTES >= 4 * 128 * 64 * 4, "the K parts' sums meet in the ring's memory");
+};
+
+template <int ZOFF, bool SPLIT, int STAGES, int D>
+__global__ __launch_bounds__(512) void q4_gemm_dma2_kernel(
+    const _Float16* __restrict__ x, const uint32_t* __restrict__ qw,
+    const uint32_t* __restrict__ qz, const _Float16* __restrict__ scales, void* __restrict__ outp,
+    int m, int n, int k, int group_size, int k_per_split) {
+  using L = Q4Dma2<STAGES>;
+  constexpr int MT = 4, NT = 2;
+  static_assert(D >= 1 && STAGES >= D + 1 && STAGES <= 3 && L::PER_TILE * (D - 1) < 64, "ring depth");
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];   // the only LDS object: offset 0
+
+#ifdef VLA_Q4_STAMP
+  const uint64_t st_entry = __builtin_amdgcn_s_memrealtime();
+#endif
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wn = wave & 3, wk = wave >> 2;                 // column wave, K part
+  const int h = lane >> 5, c = lane & 31;
+  const int n0 = blockIdx.x * 256, m0 = blockIdx.y * 128;
+  const int k_part = k_per_split / 2;                      // the host keeps this whole groups
+  const int k_begin = blockIdx.z * k_per_split + wk * k_part;
+  const int nsteps = k_part / TK;                          // the same for both parts
+  if (nsteps <= 0) return;
+  const int wcol0 = n0 + 64 * wn;                          // first column of this wave
+
+  // ---- what this lane fetches (columns past n: clamped to column 0, never stored)
+  uint32_t xoff[4], wlane[2];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int r = (wn * 4 + j) * 8 + (lane >> 3);
+    const int q = (lane & 7) ^ ((r >> 1) & 7);
+    xoff[j] = (uint32_t)(min(m0 + r, m - 1) * k + 8 * q) * 2u;       // M K < 2^30 (host check)
+  }
+#pragma unroll
+  for (int g = 0; g < NT; ++g) {
+    const int r = lane >> 3, col = wcol0 + 32 * g + 4 * (lane & 7);
+    wlane[g] = (uint32_t)(r * n + (col < n ? col : 0)) * 4u;
+  }
+  const unsigned char* zsrc;                               // walks one group per `zs_stride`
+  uint32_t zs_stride;
+  if (lane < 32 || lane >= 40) {                           // scale pairs (lanes 40.. repeat them)
+    const int col = wcol0 + 2 * (lane & 31);
+    zsrc = reinterpret_cast<const unsigned char*>(scales) + (size_t)(col < n ? col : 0) * 2;
+    zs_stride = (uint32_t)n * 2u;
+  } else {                                                 // lanes 32..39: zero words
+    const int col = wcol0 + 8 * (lane & 7);
+    zsrc = reinterpret_cast<const unsigned char*>(qz) + (size_t)((col < n ? col : 0) >> 3) * 4;
+    zs_stride = (uint32_t)(n >> 3) * 4u;
+  }
+  zsrc += (size_t)(k_begin / group_size) * zs_stride;
+  uint64_t xbase = reinterpret_cast<uint64_t>(x) + (uint64_t)k_begin * 2u;
+  uint64_t wbase = reinterpret_cast<uint64_t>(qw) + (uint64_t)(k_begin >> 3) * (uint64_t)n * 4u;
+  const uint64_t wstep = (uint64_t)(TK / 8) * (uint64_t)n * 4u;
+  const int steps_per_group = group_size / TK;
+  int group_left = steps_per_group - (k_begin / TK) % steps_per_group;
+  const uint32_t part0 = (uint32_t)(wk * L::PART);
+  const uint32_t xdst0 = part0 + (uint32_t)(wn * 4096), wdst0 = part0 + (uint32_t)(L::XB + wn * 2048),
+                 zdst0 = part0 + (uint32_t)(L::XB + L::WB + wn * 256);
+  auto issue = [&](int stage) {
+    const uint32_t base = (uint32_t)(stage * L::STAGE);
+    glds_tile2(xoff, xbase, base + xdst0, wlane, wbase, base + wdst0, zsrc, base + zdst0);
+    xbase += TK * 2;
+    wbase += wstep;
+    if (--group_left == 0) {
+      group_left = steps_per_group;
+      zsrc += zs_stride;
+    }
+  };
+
+  // ---- what this lane reads
+  const int pbase = wk * L::PART;
+  const int woff = pbase + L::XB + wn * 2048 + h * 128 + c * 4;     // + 1024 g + 256 s
+  const int zsb = pbase + L::XB + L::WB + wn * 256;
+  const int soff = zsb + 4 * (c >> 1), zoff = zsb + 128 + 4 * (c >> 3);   // + 64 g, + 16 g
+  const int zshift = 4 * (c & 7);
+  const uint32_t ssel = (c & 1) ? 0x03020302u : 0x01000100u;
+  const int aoff = pbase + c * 128;                        // + a 4096 + ((2 s + h) ^ cs) << 4
+  const int cs = (c >> 1) & 7;
+
+  f32x16 acc[NT][MT];
+#pragma unroll
+  for (int g = 0; g < NT; ++g)
+#pragma unroll
+    for (int a = 0; a < MT; ++a)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[g][a][i] = 0.f;
+
+  const f16x2 sixteenth = {(_Float16)0.0625f, (_Float16)0.0625f};
+  uint32_t c1024 = 0x64006400u;
+  asm volatile("" : "+v"(c1024));
+  constexpr uint32_t kLoMask = 0x000f000fu, kHiMask = 0x00f000f0u;
+  auto and_or = [](uint32_t a, uint32_t msk, uint32_t cc) { return (a & msk) | cc; };
+
+  struct Words { uint32_t w[NT][4], sw[NT], zw[NT]; };     // a tile's raw words of this lane
+  struct Consts { f16x2 zc1, zc2, sc2; };
+  auto load_words = [&](const unsigned char* st, Words& d) {
+#pragma unroll
+    for (int g = 0; g < NT; ++g) {
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+        d.w[g][s] = *reinterpret_cast<const uint32_t*>(st + woff + 1024 * g + 256 * s);
+      d.sw[g] = *reinterpret_cast<const uint32_t*>(st + soff + 64 * g);
+      d.zw[g] = *reinterpret_cast<const uint32_t*>(st + zoff + 16 * g);
+    }
+  };
+  auto make_consts = [&](const Words& d, int g) {
+    const uint32_t z = ((d.zw[g] >> zshift) & 15u) + ZOFF;
+    Consts r;
+    r.zc1 = as_h2((z * 0x00010001u) | 0xE400E400u);
+    r.zc2 = as_h2((z * 0x00100010u) | 0xD400D400u);
+    r.sc2 = as_h2(__builtin_amdgcn_perm(d.sw[g], d.sw[g], ssel));
+    return r;
+  };
+  auto read_a = [&](const unsigned char* st, int s, u32x4 (&af)[MT]) {
+#pragma unroll
+    for (int a = 0; a < MT; ++a)
+      af[a] = *reinterpret_cast<const u32x4*>(st + aoff + a * 4096 + (((2 * s + h) ^ cs) << 4));
+  };
+  auto dequant = [&](uint32_t wv, const Consts& q) {
+    const uint32_t w8 = wv >> 8;
+    const f16x2 d0 = as_h2(and_or(wv, kLoMask, c1024)) + q.zc1;
+    const f16x2 d1 = __builtin_elementwise_fma(as_h2(and_or(wv, kHiMask, c1024)), sixteenth, q.zc2);
+    const f16x2 d2 = as_h2(and_or(w8, kLoMask, c1024)) + q.zc1;
+    const f16x2 d3 = __builtin_elementwise_fma(as_h2(and_or(w8, kHiMask, c1024)), sixteenth, q.zc2);
+    u32x4 bf;
+    bf[0] = as_u32(d0 * q.sc2);
+    bf[1] = as_u32(d1 * q.sc2);
+    bf[2] = as_u32(d2 * q.sc2);
+    bf[3] = as_u32(d3 * q.sc2);
+    return bf;
+  };
+  auto mma2 = [&](const u32x4 (&af)[MT], const u32x4& bf0, const u32x4& bf1) {
+#pragma unroll
+    for (int a = 0; a < MT; ++a) {
+      acc[0][a] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, bf0),
+                                                         __builtin_bit_cast(f16x8, af[a]), acc[0][a],
+                                                         0, 0, 0);
+      acc[1][a] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, bf1),
+                                                         __builtin_bit_cast(f16x8, af[a]), acc[1][a],
+                                                         0, 0, 0);
+    }
+  };
+#define VLA_SB __builtin_amdgcn_sched_barrier(0)
+  Words wd;                                                // words of the tile about to be computed
+  auto step = [&](auto stage_c, int t) {
+    constexpr int ST = decltype(stage_c)::value;
+    const unsigned char* st = lds + ST * L::STAGE;
+    const unsigned char* stn = lds + ((ST + 1) % STAGES) * L::STAGE;
+    const Consts q0 = make_consts(wd, 0), q1 = make_consts(wd, 1);
+    u32x4 fa[MT], fb[MT];
+    read_a(st, 0, fa);
+    u32x4 p0 = dequant(wd.w[0][0], q0), p1 = dequant(wd.w[1][0], q1);
+    VLA_SB;
+    read_a(st, 1, fb);
+    VLA_SB;
+    mma2(fa, p0, p1);
+    u32x4 r0 = dequant(wd.w[0][1], q0), r1 = dequant(wd.w[1][1], q1);
+    VLA_SB;
+    if (t + D < nsteps) issue((ST + D) % STAGES);          // behind the first MFMAs, not before them
+    VLA_SB;
+    read_a(st, 2, fa);
+    VLA_SB;
+    mma2(fb, r0, r1);
+    p0 = dequant(wd.w[0][2], q0);
+    p1 = dequant(wd.w[1][2], q1);
+    VLA_SB;
+    read_a(st, 3, fb);
+    VLA_SB;
+    mma2(fa, p0, p1);
+    r0 = dequant(wd.w[0][3], q0);
+    r1 = dequant(wd.w[1][3], q1);
+    VLA_SB;
+    mma2(fb, r0, r1);
+    VLA_SB;
+    if (t + D < nsteps) wait_vmcnt<L::PER_TILE * (D - 1)>(); else wait_vmcnt<0>();
+    if (t + 1 < nsteps) load_words(stn, wd);               // this wave's own bytes: no barrier needed
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  };
+#undef VLA_SB
+
+  // ---- prologue: tiles 0 .. D - 1 requested, tile 0 landed
+#pragma unroll
+  for (int j = 0; j < D; ++j)
+    if (j < nsteps) issue(j);
+  if (D <= nsteps) wait_vmcnt<L::PER_TILE * (D - 1)>(); else wait_vmcnt<0>();
+  load_words(lds, wd);
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+#ifdef VLA_Q4_STAMP
+  const uint64_t st_c0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1 % STAGES>;
+  using I2 = std::integral_constant<int, 2 % STAGES>;
+  {
+    int t = 0;
+    for (; t + STAGES <= nsteps; t += STAGES) {
+      step(I0{}, t);
+      step(I1{}, t + 1);
+      if constexpr (STAGES >= 3) step(I2{}, t + 2);
+    }
+    if (t < nsteps) step(I0{}, t);
+    if (t + 1 < nsteps) step(I1{}, t + 1);
+  }
+#ifdef VLA_Q4_STAMP
+  const uint64_t st_c1 = __builtin_amdgcn_s_memtime(), st_r1 = __builtin_amdgcn_s_memrealtime();
+#endif
+
+  // ---- the second K part hands its sums to the first through LDS (the ring is free: every wave
+  // has passed the last step's barrier with all its requests landed)
+  {
+    float* red = reinterpret_cast<float*>(lds) + wn * (NT * MT * 16 * 64) + lane;
+    if (wk == 1) {
+#pragma unroll
+      for (int g = 0; g < NT; ++g)
+#pragma unroll
+        for (int a = 0; a < MT; ++a)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) red[((g * MT + a) * 16 + i) * 64] = acc[g][a][i];
+    }
+    __syncthreads();
+    if (wk == 1) return;
+#pragma unroll
+    for (int g = 0; g < NT; ++g)
+#pragma unroll
+      for (int a = 0; a < MT; ++a)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[g][a][i] += red[((g * MT + a) * 16 + i) * 64];
+  }
+#pragma unroll
+  for (int g = 0; g < NT; ++g)
+    store_tile<SPLIT, MT>(acc[g], outp, m0 + c, m, wcol0 + 32 * g + 4 * h, n,
+                          SPLIT ? (int64_t)blockIdx.z * m : (int64_t)0);
+#ifdef VLA_Q4_STAMP
+  {
+    wait_vmcnt<0>();
+    const uint64_t st_end = __builtin_amdgcn_s_memrealtime();
+    if (lane == 0 && (wave == 0 || wave == 3) && blockIdx.z == 0 && ((blockIdx.x + 3 * blockIdx.y) % 37) == 0)
+      printf("stamp2 wg %d,%d wave %d steps %d entry %llu loop0 +%llu loop1 +%llu end +%llu MHz %.0f cyc/step %.0f\n",
+             blockIdx.x, blockIdx.y, wave, nsteps, (unsigned long long)(st_entry % 100000000ull),
+             (unsigned long long)(st_r0 - st_entry), (unsigned long long)(st_r1 - st_entry),
+             (unsigned long long)(st_end - st_entry),
+             100.0 * (double)(st_c1 - st_c0) / (double)(st_r1 - st_r0), (double)(st_c1 - st_c0) / nsteps);
+  }
+#endif
 }
 
 // out[i] = fp16(sum over splits of slab[s][i]); 4 elements per thread
@@ -679,6 +1306,48 @@ static Q4Shape pick_shape(int m, int n, int k, int group) {
   return s;
 }
 
+// The LDS-DMA kernel's ring is dynamic LDS beyond the 64 KiB a kernel gets by default: the limit
+// is raised once per device and instantiation.
+template <int Z, bool SP, int NW, int ST, int D>
+static hipError_t launch_dma(dim3 grid, hipStream_t s, const _Float16* x, const uint32_t* qw,
+                             const uint32_t* qz, const _Float16* sc, void* dst, int m, int n, int k,
+                             int group, int kps) {
+  using L = Q4Dma<NW, ST>;
+  auto fn = q4_gemm_dma_kernel<Z, SP, NW, ST, D>;
+  static std::atomic<uint64_t> ready{0};
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  if (!((ready.load(std::memory_order_acquire) >> (dev & 63)) & 1)) {
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, L::BYTES);
+    if (e != hipSuccess) return e;
+    ready.fetch_or(1ull << (dev & 63), std::memory_order_release);
+  }
+  hipLaunchKernelGGL(fn, grid, dim3(64 * NW), L::BYTES, s, x, qw, qz, sc, dst, m, n, k, group, kps);
+  return hipSuccess;
+}
+
+template <int Z, bool SP, int ST, int D>
+static hipError_t launch_dma2(dim3 grid, hipStream_t s, const _Float16* x, const uint32_t* qw,
+                              const uint32_t* qz, const _Float16* sc, void* dst, int m, int n, int k,
+                              int group, int kps) {
+  using L = Q4Dma2<ST>;
+  auto fn = q4_gemm_dma2_kernel<Z, SP, ST, D>;
+  static std::atomic<uint64_t> ready{0};
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  if (!((ready.load(std::memory_order_acquire) >> (dev & 63)) & 1)) {
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, L::BYTES);
+    if (e != hipSuccess) return e;
+    ready.fetch_or(1ull << (dev & 63), std::memory_order_release);
+  }
+  hipLaunchKernelGGL(fn, grid, dim3(512), L::BYTES, s, x, qw, qz, sc, dst, m, n, k, group, kps);
+  return hipSuccess;
+}
+
 extern "C" int64_t vla_q4_gemm_workspace_bytes(int m, int n, int k, int group) {
   if (m <= 0 || n <= 0 || k <= 0 || group <= 0) return 0;
   const int s = pick_shape(m, n, k, group).splits;
@@ -702,8 +1371,16 @@ static int q4_gemm_run(const void* x, const int32_t* qweight, const int32_t* qze
   hipStream_t s = (hipStream_t)stream;
   const bool m32 = group % TK == 0;                  // the 32x32 kernel wants whole K steps per group
   static const bool g2_enabled = !(getenv("VLA_Q4_G2") && atoi(getenv("VLA_Q4_G2")) == 0);  // kernel studies
+  // 128-row tiles: the LDS-DMA kernels.  VLA_Q4_DMA (kernel studies): 0 the register-staged kernel,
+  // 3 / 4 the 128 x 32 wave tile over that many ring stages, 23 the 128 x 64 wave tile wherever it
+  // fits; unset: 128 x 64 wave tiles for unsliced layers whose K parts are at least 16 steps
+  // (gate_up 4096 x 28672 at batch 256: 74 -> 69 us), 128 x 32 tiles over 3 stages otherwise
+  // (qkv / o / down: 30.3 / 25.2 / 45.5 -> 29.3 / 24.6 / 44.3 us).
+  static const int dma_env = getenv("VLA_Q4_DMA") ? atoi(getenv("VLA_Q4_DMA")) : -1;
+  const bool dma_ok = (int64_t)m * k < (1ll << 30) && (int64_t)n * 32 < (1ll << 30);   // 32-bit lane offsets
   Q4Shape shape = pick_shape(m, n, k, group);
   int splits = shape.splits;
+  int dma_stages = dma_env;            // decided below, once the slicing is final
   if (splits > 1 && (!workspace || workspace_bytes < (int64_t)splits * m * n * 4 ||
                      ((uintptr_t)workspace % 16) || ((int64_t)m * n) % 4))
     splits = 1;
@@ -711,6 +1388,9 @@ static int q4_gemm_run(const void* x, const int32_t* qweight, const int32_t* qze
   dim3 grid((n + tn - 1) / tn, (m + tm - 1) / tm, splits);
   const int kps = k / splits;
   void* dst = splits > 1 ? workspace : out;
+  const bool parts_ok = kps % (2 * (group > TK ? group : TK)) == 0;   // two K parts of whole groups
+  if (dma_env < 0) dma_stages = (splits == 1 && shape.nw == 8 && parts_ok && kps / (2 * TK) >= 16) ? 23 : 3;
+  if (dma_stages == 23 && !(shape.nw == 8 && parts_ok)) dma_stages = 3;
 #define VLA_Q4_ARGS                                                                            \
   (const _Float16*)x, (const uint32_t*)qweight, (const uint32_t*)qzeros, (const _Float16*)scales, \
       dst, m, n, k, group, kps
@@ -732,6 +1412,16 @@ static int q4_gemm_run(const void* x, const int32_t* qweight, const int32_t* qze
       VLA_Q4_LAUNCH_KW(Z, SP, G2, 1);                                                          \
     else if (shape.mt == 2)                                                                    \
       VLA_Q4_LAUNCH_KW(Z, SP, G2, 2);                                                          \
+    else if (dma_ok && dma_stages == 23 && shape.nw == 8 && parts_ok)                          \
+      VLA_HIP_CHECK((launch_dma2<Z, SP, 3, 2>(grid, s, VLA_Q4_ARGS)));                         \
+    else if (dma_ok && dma_stages == 3 && shape.nw == 8)                                       \
+      VLA_HIP_CHECK((launch_dma<Z, SP, 8, 3, 2>(grid, s, VLA_Q4_ARGS)));                       \
+    else if (dma_ok && dma_stages == 3 && shape.nw == 4)                                       \
+      VLA_HIP_CHECK((launch_dma<Z, SP, 4, 3, 2>(grid, s, VLA_Q4_ARGS)));                       \
+    else if (dma_ok && dma_stages == 4 && shape.nw == 8)                                       \
+      VLA_HIP_CHECK((launch_dma<Z, SP, 8, 4, 3>(grid, s, VLA_Q4_ARGS)));                       \
+    else if (dma_ok && dma_stages == 4 && shape.nw == 4)                                       \
+      VLA_HIP_CHECK((launch_dma<Z, SP, 4, 4, 3>(grid, s, VLA_Q4_ARGS)));                       \
     else if (shape.nw == 8)                                                                    \
       hipLaunchKernelGGL((q4_gemm_m32_kernel<Z, SP, 8, 4, false, G2>), grid, dim3(512), 0, s,  \
                          VLA_Q4_ARGS);                                                         \
