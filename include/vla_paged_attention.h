@@ -52,6 +52,12 @@ int vla_abi_version(void);
 /* Test hook, no counterpart in the reference: 0 = choose the attention kernel per shape
  * (default), 1 = always run the generic kernel. Process-wide. */
 int vla_set_attention_path(int mode);
+/* No counterpart in the reference.  Cache policy of the K / V loads of the MFMA attention
+ * kernel: 0 = by size (default: nontemporal loads when the launch reads more than the 256 MiB the
+ * Infinity Cache holds, num_seqs x max_seq_len tokens of K and V), 1 = always nontemporal, 2 =
+ * never.  Results do not depend on it.  Process-wide; the environment variable
+ * VLA_KV_LOAD_POLICY sets the initial value. */
+int vla_set_kv_load_policy(int mode);
 /* "auto" -> VLA_KV_AUTO, "fp8" / "fp8_e4m3" -> VLA_KV_FP8_E4M3, anything else -> -1
  * (DISPATCH_BY_KV_CACHE_DTYPE, csrc/quantization/fp8/amd/quant_utils.cuh:545-571). */
 int vla_kv_dtype_from_string(const char* name);

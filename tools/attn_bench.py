@@ -36,6 +36,8 @@ def main():
     ap.add_argument("--generic", action="store_true", help="force the coverage kernel")
     ap.add_argument("--graph", action="store_true",
                     help="time the launches replayed from one HIP graph (no host launch cost)")
+    ap.add_argument("--kv-policy", type=int, default=0,
+                    help="K/V load policy: 0 by size, 1 nontemporal, 2 default cache policy")
     ap.add_argument("--pool", type=int, default=0,
                     help="the reference harness's set-up (benchmarks/kernels/benchmark_paged_attention.py"
                          ":11, :59-63): a cache of this many blocks, block tables drawn from it with "
@@ -46,6 +48,8 @@ def main():
     B, S, BS, D = a.batch, a.seq, a.block, a.head_size
     if a.generic:
         ops.set_attention_path(1)
+    if a.kv_policy:
+        ops.set_kv_load_policy(a.kv_policy)
     nb = a.pool if a.pool else B * (S // BS)
     g = torch.Generator(device=dev).manual_seed(0)
     scale = D**-0.5

@@ -693,3 +693,10 @@ def get_max_shared_memory_per_block_device_attribute(device: int = 0) -> int:
 def set_attention_path(mode: int) -> None:
     """Test hook: 0 = pick the kernel per shape, 1 = force the generic kernel."""
     check(_lib.lib().vla_set_attention_path(mode))
+
+
+def set_kv_load_policy(mode: int) -> None:
+    """Cache policy of the attention kernel's K / V loads: 0 by size (default), 1 always
+    nontemporal, 2 never.  A cache that stays resident between launches (a benchmark over a small
+    block pool) is read faster without the hint; results are the same either way."""
+    check(_lib.lib().vla_set_kv_load_policy(mode))

@@ -39,6 +39,25 @@ extern "C" int vla_set_attention_path(int mode) {
   g_attention_path = mode;
   return VLA_OK;
 }
+// K / V load policy of the MFMA attention kernel: 0 by size (nontemporal when the launch reads
+// more than the 256 MiB of Infinity Cache can hold, i.e. when nothing it reads will be read again
+// from cache), 1 always nontemporal, 2 never.
+static int g_kv_load_policy = [] {
+  const char* e = getenv("VLA_KV_LOAD_POLICY");
+  const int v = e ? atoi(e) : 0;
+  return v >= 0 && v <= 2 ? v : 0;
+}();
+extern "C" int vla_set_kv_load_policy(int mode) {
+  if (mode < 0 || mode > 2) return VLA_ERR_ARG;
+  g_kv_load_policy = mode;
+  return VLA_OK;
+}
+static int kv_nontemporal(int num_seqs, int max_tokens, int num_kv_heads, int head_size, int kv_dtype) {
+  if (g_kv_load_policy != 0) return g_kv_load_policy == 1;
+  const int64_t bytes = (int64_t)num_seqs * max_tokens * num_kv_heads * head_size * 2 *
+                        (kv_dtype == VLA_KV_FP8_E4M3 ? 1 : 2);
+  return bytes > (256ll << 20);
+}
 extern "C" int vla_abi_version(void) { return 1; }
 
 extern "C" int vla_kv_dtype_from_string(const char* name) {
@@ -80,7 +99,6 @@ extern "C" int vla_paged_attention_v1_ordered(
     int blocksparse_vert_stride, int blocksparse_block_size, int blocksparse_head_sliding_step,
     const int* seq_order, void* stream) {
   (void)hipGetLastError();  // a stale error of some earlier HIP call must not fail this one
-  (void)max_seq_len;
   if (blocksparse_vert_stride > 1 && blocksparse_block_size <= 0) return VLA_ERR_BLOCKSPARSE;
   int rc = check_attn(out, query, key_cache, value_cache, num_seqs, num_heads, num_kv_heads,
                       head_size, block_size, block_tables, seq_lens, max_num_blocks_per_seq,
@@ -99,6 +117,9 @@ extern "C" int vla_paged_attention_v1_ordered(
   p.bs_block_size = blocksparse_block_size; p.bs_head_sliding_step = blocksparse_head_sliding_step;
   p.tp_rank = tp_rank;
   p.seq_order = seq_order;
+  p.kv_nontemporal = kv_nontemporal(
+      num_seqs, max_seq_len > 0 ? max_seq_len : max_num_blocks_per_seq * block_size, num_kv_heads,
+      head_size, kv_dtype);
   hipStream_t s = (hipStream_t)stream;
   // the block-sparse variant (vert_stride > 1, ref attention_kernels.cu:821) runs on the generic
   // kernel only
@@ -155,6 +176,7 @@ extern "C" int vla_paged_attention_v2_ordered(
   p.bs_block_size = blocksparse_block_size; p.bs_head_sliding_step = blocksparse_head_sliding_step;
   p.tp_rank = tp_rank;
   p.seq_order = seq_order;
+  p.kv_nontemporal = kv_nontemporal(num_seqs, max_seq_len, num_kv_heads, head_size, kv_dtype);
   hipStream_t s = (hipStream_t)stream;
   const bool generic_only = g_attention_path == 1 || blocksparse_vert_stride > 1;
   rc = generic_only ? -1 : launch_paged_attention_mfma(p, dtype, kv_dtype, s);

@@ -33,12 +33,29 @@
 // accumulation, normaliser 1 / (sum + 1e-6) (:342).  fp8 bytes convert exactly to fp16/bf16;
 // kv_scale is folded into the logit scale and the output instead of being multiplied into
 // every element (identical when kv_scale == 1).
+#include <type_traits>
+
 #include "vla_common.h"
+
+
 
 #include <math.h>
 
 namespace vla {
 namespace {
+
+// K and V are read once per launch, by exactly one workgroup (the whole GQA group of a KV head
+// shares it).  With the nontemporal hint on those loads a launch over batch 256 x 4096 tokens of
+// fp8 cache takes 0.335 ms instead of 0.370 (6.4 against 5.8 TB/s); a cache small enough to stay
+// resident is faster without it, so the launch chooses (AttnParams::kv_nontemporal).
+template <bool NT>
+__device__ __forceinline__ u32x4 kv_load(const unsigned char* p) {
+  if constexpr (NT)
+    return __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
+  else
+    return *reinterpret_cast<const u32x4*>(p);
+}
+
 
 constexpr int kThreads = 256;
 constexpr int kWaves = 4;
@@ -90,7 +107,9 @@ __device__ __forceinline__ u32x4 mask_tokens(u32x4 v, int nvalid) {
 
 // D: head size (a multiple of 16; the q.K contraction is padded with zero query dims up to the
 // next multiple of 4 K chunks), BS: KV block size (16 or 32).
-template <class S, bool FP8, int D, int BS, bool PARTITIONED>
+// KVNT: nontemporal K / V loads (a template parameter: behind a run-time branch the compiler
+// merges the two otherwise identical load groups and drops the hint)
+template <class S, bool FP8, int D, int BS, bool PARTITIONED, bool KVNT>
 __global__ __launch_bounds__(kThreads, 2) void pa_mfma_kernel(AttnParams p, int heads_per_wg) {
   using T = typename S::T;
   constexpr int kBS = BS;
@@ -187,8 +206,7 @@ __global__ __launch_bounds__(kThreads, 2) void pa_mfma_kernel(AttnParams p, int 
       const unsigned char* kp = kbase + (int64_t)blk[t] * blk_bytes + k_lane_off +
                                 ((16 * t) % kBS) * 16;
 #pragma unroll
-      for (int j = 0; j < KL; ++j)
-        kb[t * KL + j] = *reinterpret_cast<const u32x4*>(kp + k_j_off[j]);
+      for (int j = 0; j < KL; ++j) kb[t * KL + j] = kv_load<KVNT>(kp + k_j_off[j]);
     }
   };
 
@@ -221,8 +239,7 @@ __global__ __launch_bounds__(kThreads, 2) void pa_mfma_kernel(AttnParams p, int 
       }
       const unsigned char* vp = vbase + (int64_t)vblk * blk_bytes + v_lane_off;
 #pragma unroll
-      for (int n = 0; n < ND; ++n)
-        vb[n] = *reinterpret_cast<const u32x4*>(vp + n * (16 * kBS * CE));
+      for (int n = 0; n < ND; ++n) vb[n] = kv_load<KVNT>(vp + n * (16 * kBS * CE));
     }
 
     // ---- logits: NT tiles of 16 tokens x 16 heads
@@ -378,10 +395,17 @@ int launch_b(const AttnParams& p, hipStream_t s) {
   if (smem > 64 * 1024) return -1;  // beyond the default dynamic-LDS limit: generic kernel
   dim3 grid(p.num_kv_heads * groups_per_kv, p.num_seqs,
             p.max_num_partitions > 0 ? p.max_num_partitions : 1);
-  if (p.max_num_partitions > 0)
-    hipLaunchKernelGGL((pa_mfma_kernel<S, FP8, D, BS, true>), grid, dim3(kThreads), smem, s, p, hpw);
-  else
-    hipLaunchKernelGGL((pa_mfma_kernel<S, FP8, D, BS, false>), grid, dim3(kThreads), smem, s, p, hpw);
+  if (p.max_num_partitions > 0) {
+    if (p.kv_nontemporal)
+      hipLaunchKernelGGL((pa_mfma_kernel<S, FP8, D, BS, true, true>), grid, dim3(kThreads), smem, s, p, hpw);
+    else
+      hipLaunchKernelGGL((pa_mfma_kernel<S, FP8, D, BS, true, false>), grid, dim3(kThreads), smem, s, p, hpw);
+  } else {
+    if (p.kv_nontemporal)
+      hipLaunchKernelGGL((pa_mfma_kernel<S, FP8, D, BS, false, true>), grid, dim3(kThreads), smem, s, p, hpw);
+    else
+      hipLaunchKernelGGL((pa_mfma_kernel<S, FP8, D, BS, false, false>), grid, dim3(kThreads), smem, s, p, hpw);
+  }
   VLA_HIP_CHECK(hipGetLastError());
   return VLA_OK;
 }

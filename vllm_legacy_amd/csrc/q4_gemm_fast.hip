@@ -330,7 +330,7 @@ __global__ __launch_bounds__(64 * NW * KW) void q4_gemm_m32_kernel(
   // loads per step cost as much issue time as the weight words themselves.
   struct ZS { uint32_t z; uint32_t s; };
   struct WStep { uint32_t w[4]; ZS zs; };
-  const int last_group = (k_end - 1) / group_size, group0 = k_begin / group_size;
+  const int last_group = (k_end - 1) / group_size;
   auto load_zs = [&](int grp, ZS& d) {
     grp = min(grp, last_group);
     d.z = zsrc[(int64_t)grp * (n >> 3)];
@@ -339,8 +339,17 @@ __global__ __launch_bounds__(64 * NW * KW) void q4_gemm_m32_kernel(
   auto load_w = [&](int step, WStep& d) {
     const int k0 = k_begin + phys(step) * TK;
     const uint32_t* p = wsrc + (int64_t)(k0 >> 3) * n;
+    // An unsliced small-batch launch (K parts inside the workgroup only: the widest layers) reads
+    // every weight word exactly once: nontemporal there (gate_up 4096 x 28672 at batch 1: 22.5 ->
+    // 19.3 us).  Sliced launches lose with the hint (qkv at batch 128: 22.7 -> 26.2 us).
+    constexpr bool WNT = !SPLIT && KW == 4;
 #pragma unroll
-    for (int s = 0; s < 4; ++s) d.w[s] = p[(int64_t)(2 * s) * n];
+    for (int s = 0; s < 4; ++s) {
+      if constexpr (WNT)
+        d.w[s] = __builtin_nontemporal_load(p + (int64_t)(2 * s) * n);
+      else
+        d.w[s] = p[(int64_t)(2 * s) * n];
+    }
     if constexpr (!G2) load_zs(k0 / group_size, d.zs);
   };
 
@@ -866,6 +875,8 @@ __global__ __launch_bounds__(64 * NW) void q4_gemm_dma_kernel(
 // of a step simply issued twice the matrix pipe's share rose from 0.62 to 0.79.
 // The workgroup tile (128 x 256), the grid and the K slicing across workgroups stay as they are.
 // Each K part has its own x ring (its 4 waves fill and read it); the barrier is the workgroup's.
+// The weight words are requested nontemporal: an unsliced launch reads each of them once per row
+// tile and nothing else will (gate_up at batch 256: 72.7 -> 69.5 us).
 __device__ __forceinline__ void glds_tile2(const uint32_t (&xoff)[4], uint64_t xbase, uint32_t xdst,
                                            const uint32_t (&woff)[2], uint64_t wbase, uint32_t wdst,
                                            const void* zsrc, uint32_t zdst) {
@@ -876,8 +887,8 @@ __device__ __forceinline__ void glds_tile2(const uint32_t (&xoff)[4], uint64_t x
       "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %11\n\t"
       "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %11\n\t"
       "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, %11\n\t"
-      "s_mov_b32 m0, %8\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %6, %12\n\t"
-      "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %7, %12\n\t"
+      "s_mov_b32 m0, %8\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %6, %12 nt\n\t"
+      "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %7, %12 nt\n\t"
       "s_mov_b32 m0, %10\n\ts_nop 0\n\tglobal_load_lds_dword %9, off\n\t"
       "s_mov_b32 m0, %0"
       : "=&s"(keep)

@@ -136,6 +136,9 @@ struct AttnParams {
   // block-sparse attention (ref attention_kernels.cu:209-254); bs_vert_stride <= 1 = dense
   int bs_vert_stride = 0, bs_local_blocks = 0, bs_block_size = 64, bs_head_sliding_step = 0;
   int tp_rank = 0;
+  // K / V loads carry the nontemporal hint (every byte is read once, by one workgroup): set by
+  // the entry points from vla_set_kv_load_policy and the size of what the launch will read
+  int kv_nontemporal = 0;
 };
 
 // implemented in paged_attention_generic.hip / paged_attention_mfma.hip
