@@ -33,7 +33,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
-HBM_MEASURED_READ_GBS = 6353.0  # linear read-only stream measured on the part
+HBM_MEASURED_READ_GBS = 7184.0  # linear read-only stream with nontemporal loads measured on the part (6409 with default-policy loads; tools/exp/read_bw.hip)
 MFMA_F16_PEAK_TFLOPS = 2500.0   # dense fp16/bf16 MFMA peak of the part
 
 
