@@ -14,6 +14,7 @@ rocprofv3 in KiB, and on gfx950 FETCH_SIZE counts 64-byte requests as 32 bytes, 
 columns apply x1024 and (for FETCH_SIZE) x2.
 """
 import csv
+import re
 import collections
 import sys
 
@@ -93,7 +94,7 @@ def gemm_traffic(fetch_csv, write_csv, dst, note):
     def per_kernel(path, counter):
         out = {}
         for r in csv.DictReader(open(path)):
-            if r["Counter"].startswith(counter) and "q4_gemm_m32_kernel" in r["Kernel"]:
+            if r["Counter"].startswith(counter) and re.search(r"q4_gemm_(m32|dma2?)_kernel", r["Kernel"]):
                 out[r["Kernel"]] = (float(r["AvgBytes(corrected)"]), int(r["Dispatches"]))
         return out
 
@@ -108,7 +109,8 @@ def gemm_traffic(fetch_csv, write_csv, dst, note):
     for name in f:
         fb, n = f[name]
         wb = w.get(name, (0.0, 0))[0]
-        split = "ELb1E" in name.split("q4_gemm_m32_kernel")[1][:12]
+        # template arguments <ZOFF, SPLIT, ...>: ILi<z>ELb<split>E...
+        split = re.search(r"q4_gemm_\w+?_kernelILi\dELb(\d)E", name).group(1) == "1"
         launches = 3 if split else 1
         rec["kernels"][name] = {"fetch_bytes": round(fb), "write_bytes": round(wb), "dispatches": n,
                                 "launches_per_layer": launches}
