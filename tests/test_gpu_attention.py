@@ -400,3 +400,38 @@ def test_sequence_order_does_not_change_results(ops, version, head_size, block_s
     for o in (order, torch.randperm(33, device="cuda").to(torch.int32)):
         got = T.run_hip_attention(ops, c, version, seq_order=o)
         assert torch.equal(got.view(torch.int16), base.view(torch.int16))
+
+
+@pytest.mark.parametrize("version", ["v1", "v2"])
+@pytest.mark.parametrize("kv_fp8", [False, True])
+def test_kv_load_policy_does_not_change_results(ops, version, kv_fp8):
+    # nontemporal or default-policy K/V loads (vla_set_kv_load_policy; no counterpart in the
+    # reference) is a cache hint: the output must be the same bits, and right
+    c = T.make_attention_case(23, 5, (32, 8), 128, 16, O.DT_F16, kv_fp8, False, max_seq_len=900,
+                              num_blocks=320, seq_lens=[1, 17, 512, 513, 900])
+    want = T.oracle_attention(c, version)
+    kvd = "fp8" if kv_fp8 else "auto"
+    outs = []
+    try:
+        for policy in (1, 2, 0):
+            ops.set_kv_load_policy(policy)
+            out = torch.full_like(c.t_q, float("nan"))
+            if version == "v1":
+                ops.paged_attention_v1(out, c.t_q, c.t_kc, c.t_vc, c.hkv, c.scale, c.t_bt, c.t_sl,
+                                       c.bs, c.max_seq_len, None, kvd, 1.0)
+            else:
+                S, H, D = out.shape
+                tmp = torch.empty((S, H, 2, D), dtype=out.dtype, device="cuda")
+                es = torch.empty((S, H, 2), dtype=torch.float32, device="cuda")
+                ml = torch.empty_like(es)
+                ops.paged_attention_v2(out, es, ml, tmp, c.t_q, c.t_kc, c.t_vc, c.hkv, c.scale,
+                                       c.t_bt, c.t_sl, c.bs, c.max_seq_len, None, kvd, 1.0)
+            torch.cuda.synchronize()
+            outs.append(out)
+    finally:
+        ops.set_kv_load_policy(0)
+    assert torch.equal(outs[0].view(torch.int16), outs[1].view(torch.int16))
+    assert torch.equal(outs[0].view(torch.int16), outs[2].view(torch.int16))
+    _check(outs[0], want, O.DT_F16, kv_fp8)
+    with pytest.raises(Exception):
+        ops.set_kv_load_policy(3)
