@@ -239,6 +239,34 @@ def test_gptq_linear_method_llama70b_tp8_shapes(ops, k, n, m):
                                atol=8e-3)
 
 
+# The unsliced 128-row launches (128 x 64 wave tiles, two K parts per workgroup) at their edges:
+# a last column tile that is partly outside the matrix, a last row tile of 44 rows, 64-deep
+# groups, and the GPTQ zero convention (stored zero - 1).
+@pytest.mark.parametrize("kind,m,k,n,group", [("awq", 300, 4096, 16456, 64), ("awq", 129, 2048, 28680, 128),
+                                              ("gptq", 256, 4096, 28672, 128)])
+def test_unsliced_wide_layers_at_tile_edges(ops, kind, m, k, n, group):
+    rng = np.random.default_rng(m + n)
+    x = O.to_bits(rng.uniform(-1, 1, (m, k)).astype(np.float32), O.DT_F16)
+    if kind == "awq":
+        qw, qz, sc = _awq_weights(rng, k, n, group)
+        pw, pz = ops.awq_repack(_cuda(qw), _cuda(qz))
+        got = ops.q4_gemm_packed(_cuda(x, O.DT_F16), pw, pz, _cuda(sc, O.DT_F16), 0)
+        w = O.awq_dequantize(qw, sc, qz)
+    else:
+        qw, qz, sc = _gptq_weights(rng, k, n, group)
+        gq = _cuda(qw.copy())
+        ops.gptq_shuffle(gq, torch.empty(0, dtype=torch.int32, device="cuda"), 4)
+        got = ops.gptq_gemm(_cuda(x, O.DT_F16), gq, _cuda(qz), _cuda(sc, O.DT_F16),
+                            torch.empty(0, dtype=torch.int32, device="cuda"), True, 4)
+        w = O.gptq_dequantize(qw, qz, sc)
+    torch.cuda.synchronize()
+    assert got.shape == (m, n)
+    cols = np.unique(np.concatenate([np.arange(0, n, 13), np.arange(n - 40, n)]))   # incl. the last tile
+    want = O.gemm_f16(x, np.ascontiguousarray(w[:, cols]))
+    np.testing.assert_allclose(got[:, torch.from_numpy(cols).cuda()].float().cpu().numpy(),
+                               O.from_bits(want, O.DT_F16), rtol=3e-3, atol=8e-3)
+
+
 @pytest.mark.parametrize("k,n", [(4096, 7168), (7168, 4096)])
 def test_awq_packed_gemm_mixtral_tp2_expert_shapes(ops, k, n):
     rng = np.random.default_rng(k)
