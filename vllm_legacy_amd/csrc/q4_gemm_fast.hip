@@ -289,6 +289,10 @@ __global__ __launch_bounds__(64 * NW * KW) void q4_gemm_m32_kernel(
   const int k_end = min(k, k_begin + k_part);
   const int nsteps = k_part / TK;                // the same for every part: barriers stay in step
   if (nsteps <= 0) return;
+#ifdef VLA_Q4_STAMP   // diagnostic build: where a workgroup's time goes (100 MHz ticks)
+  const uint64_t st_entry = __builtin_amdgcn_s_memrealtime();
+  uint64_t st_first = 0;
+#endif
   auto phys = [&](int t) { return min(t, nsteps - 1); };   // past the end: re-read the last step
 
   // ---- x staging: thread -> (row = XROWS i + tid / 8, chunk tid % 8).  Rows past m are clamped
@@ -466,6 +470,9 @@ __global__ __launch_bounds__(64 * NW * KW) void q4_gemm_m32_kernel(
 #undef VLA_SB
     if (t + 1 < nsteps) store_x(buf ^ 1, xpark);
     __syncthreads();
+#ifdef VLA_Q4_STAMP
+    if (t == 0) st_first = __builtin_amdgcn_s_memrealtime();
+#endif
   };
 
   WStep w0, w1, w2, w3;
@@ -511,6 +518,9 @@ __global__ __launch_bounds__(64 * NW * KW) void q4_gemm_m32_kernel(
     if (t + 2 < nsteps) k_step(t + 2, w2, w1, xa, xb_, zb, za);
   }
 
+#ifdef VLA_Q4_STAMP
+  const uint64_t st_loop1 = __builtin_amdgcn_s_memrealtime();
+#endif
   if constexpr (DUAL) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[0][i] += acc_odd[0][i];
@@ -547,6 +557,17 @@ __global__ __launch_bounds__(64 * NW * KW) void q4_gemm_m32_kernel(
   // of four 2- or 4-byte ones (the store tail of a 128-row tile was a sixth of the kernel).
   store_tile<SPLIT, MT>(acc, outp, m0 + c, m, n0 + 32 * wn + 4 * h, n,
                         SPLIT ? (int64_t)blockIdx.z * slab_rows + row_base : (int64_t)row_base);
+#ifdef VLA_Q4_STAMP
+  {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const uint64_t st_end = __builtin_amdgcn_s_memrealtime();
+    if (threadIdx.x == 0 && ((blockIdx.x + 5 * blockIdx.y + 11 * blockIdx.z) % 61) == 0)
+      printf("stamp32 wg %d,%d,%d steps %d entry %llu first +%llu loop1 +%llu end +%llu\n", blockIdx.x,
+             blockIdx.y, blockIdx.z, nsteps, (unsigned long long)(st_entry % 100000000ull),
+             (unsigned long long)(st_first - st_entry), (unsigned long long)(st_loop1 - st_entry),
+             (unsigned long long)(st_end - st_entry));
+  }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------
