@@ -619,7 +619,9 @@ def main():
             "timing": gemm_timing,
         }
         krec = load_profile_record("kernel_times.json")
-        if krec is not None and "q4_gemm_layer_us" in krec:
+        if (krec is not None and "q4_gemm_layer_us" in krec and world == 1 and
+                krec.get("workload") == {"batch": B, "seq": S, "kv": args.kv, "model": args.model,
+                                         "quant": args.quant}):
             gemm["rocprof_layer_us"] = krec["q4_gemm_layer_us"]
             gemm["rocprof_source"] = krec.get("source")
 
@@ -636,8 +638,9 @@ def main():
     # the same kernel's average duration in the committed rocprofv3 kernel trace of this command
     rocprof_attn_us = rocprof_src = None
     krec = load_profile_record("kernel_times.json")
-    if krec is not None and krec.get("workload") == {"batch": B, "seq": S, "kv": args.kv,
-                                                     "model": args.model, "quant": args.quant}:
+    # (a single-GPU record: the per-rank shapes of a tensor-parallel run are different kernels)
+    if world == 1 and krec is not None and krec.get("workload") == {
+            "batch": B, "seq": S, "kv": args.kv, "model": args.model, "quant": args.quant}:
         rocprof_attn_us, rocprof_src = krec.get("paged_attention_us"), krec.get("source")
 
     if rank == 0:
