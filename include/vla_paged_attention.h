@@ -306,13 +306,46 @@ int vla_prefix_prefill_attention(void* out, const void* query, const void* key, 
  * (int32 [num_sets + 1] on the device, so the launch needs no host knowledge of the routing and
  * can be captured).  qweight / qzeros / scales hold the k-packed tensors of all sets back to back
  * ([num_sets, k/8, n], [num_sets, k/group, n/8], [num_sets, k/group, n]).  Rows outside every set
- * are left untouched (zero when the product is split along K).  max_rows_per_set bounds the grid;
+ * come back zero (the caller hands in a zeroed `out`; the K-split form clears its slabs).
+ * max_rows_per_set bounds the grid;
  * group a multiple of 64.  workspace: vla_q4_gemm_grouped_workspace_bytes or NULL. */
 int64_t vla_q4_gemm_grouped_workspace_bytes(int total_rows, int n, int k, int group, int num_sets);
 int vla_q4_gemm_grouped(const void* x, const int32_t* qweight, const int32_t* qzeros,
                         const void* scales, void* out, const int* row_offsets, int num_sets,
                         int total_rows, int max_rows_per_set, int n, int k, int group,
                         int zero_offset, void* workspace, int64_t workspace_bytes, void* stream);
+/* vla_q4_gemm_grouped with the gather of the routed tokens folded in: product row r reads
+ * x[x_rows[r], :] (x_rows int32 [total_rows] on the device, e.g. sorted_token of
+ * vla_moe_sort_pairs), so the expert loop's `hidden_states[tok]` copy
+ * (vllm/model_executor/models/mixtral_quant.py:141-151 runs each expert over all tokens; the
+ * routed form gathers first) is never materialised; x_rows NULL reads rows in place.  Rows
+ * outside every set are left unwritten (no slab is cleared). */
+int vla_q4_gemm_grouped_gather(const void* x, const int* x_rows, const int32_t* qweight,
+                               const int32_t* qzeros, const void* scales, void* out,
+                               const int* row_offsets, int num_sets, int total_rows,
+                               int max_rows_per_set, int n, int k, int group, int zero_offset,
+                               void* workspace, int64_t workspace_bytes, void* stream);
+
+/* Routing glue of the quantized Mixtral block (vllm/model_executor/models/mixtral_quant.py:129-156)
+ * around the two grouped products, on the device and without host synchronisation.
+ * vla_moe_sort_pairs: selected_experts int64 [num_tokens * top_k] (torch.topk's indices, :136-137);
+ * bucket_of int32 [num_experts] maps an expert to its bucket: 0 .. num_buckets - 2 for the experts
+ * this rank holds (:109-123), num_buckets - 1 for all others.  Writes row_offsets
+ * [num_buckets + 1] (rows of bucket b are row_offsets[b] .. row_offsets[b + 1], pairs of a bucket
+ * in pair order), sorted_token [pairs] (the token a sorted row belongs to), pair_row [pairs] (the
+ * sorted row of pair p = token * top_k + choice) and, unless NULL, row_bucket [pairs].
+ * VLA_ERR_ARG when pairs / 64 * num_buckets exceeds 15360 (the caller keeps a slower path).
+ * vla_moe_combine: out[t, :] = sum over the local experts e chosen by token t, ascending e, of
+ * model_dtype(y[pair_row[(t, e)], :] * routing_weights[(t, e)]), every partial sum rounded to the
+ * model dtype: `expert_layer(hidden_states).mul_(expert_weights)` and `final.add_(...)` of
+ * :141-151, where the experts a token did not choose add exact zeros.  y [pairs, hidden] fp16 /
+ * bf16, routing_weights fp32 [num_tokens * top_k], top_k <= 8, hidden a multiple of 8. */
+int vla_moe_sort_pairs(const int64_t* selected_experts, const int* bucket_of, int num_experts,
+                       int num_tokens, int top_k, int num_buckets, int* row_offsets,
+                       int* sorted_token, int* pair_row, int* row_bucket, void* stream);
+int vla_moe_combine(const void* y, const float* routing_weights, const int64_t* selected_experts,
+                    const int* pair_row, const int* bucket_of, int num_experts, int num_local,
+                    int num_tokens, int top_k, int hidden, void* out, int dtype, void* stream);
 
 /* ---- all-reduce over xGMI peer memory ---------------------------------------------------------- */
 

@@ -67,6 +67,91 @@ def test_routed_moe_matches_dense_loop_and_oracle(tokens):
     np.testing.assert_allclose(routed.float().cpu().numpy(), want, rtol=1e-2, atol=1e-2)
 
 
+@pytest.mark.parametrize("tokens,top_k,experts,local", [(1, 2, 8, 8), (37, 2, 8, 8), (256, 2, 8, 4),
+                                                        (1000, 2, 8, 8), (4096, 2, 8, 8),
+                                                        (300, 4, 64, 16), (64, 1, 8, 2)])
+def test_moe_sort_pairs_is_a_stable_bucket_sort(tokens, top_k, experts, local):
+    """Index work, bit-exact: the one-launch pair sort against a stable argsort of the bucket
+    numbers -- offsets, the token of every sorted row, the row of every pair, the bucket of every
+    row; experts of other ranks share the trailing bucket."""
+    from vllm_legacy_amd import _custom_ops as ops
+    g = torch.Generator(device="cuda").manual_seed(tokens + experts)
+    scores = torch.rand((tokens, experts), device="cuda", generator=g)
+    sel = torch.topk(scores, top_k, dim=-1).indices.contiguous()
+    lut = torch.full((experts, ), local, dtype=torch.int32)
+    owned = torch.randperm(experts, generator=torch.Generator().manual_seed(3))[:local].sort().values
+    for li, e in enumerate(owned.tolist()):
+        lut[e] = li
+    lut = lut.cuda()
+    offs, tok, pair_row, row_bucket = ops.moe_sort_pairs(sel, lut, local + 1, want_row_bucket=True)
+    bucket = lut.long()[sel.reshape(-1)]
+    order = torch.argsort(bucket, stable=True)
+    counts = torch.bincount(bucket, minlength=local + 1)
+    want_offs = torch.zeros(local + 2, dtype=torch.int64, device="cuda")
+    want_offs[1:] = torch.cumsum(counts, 0)
+    assert torch.equal(offs.long(), want_offs)
+    assert torch.equal(tok.long(), order // top_k)
+    assert torch.equal(row_bucket.long(), bucket[order])
+    inv = torch.empty_like(order)
+    inv[order] = torch.arange(order.numel(), device="cuda")
+    assert torch.equal(pair_row.long(), inv)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("tokens,top_k,local", [(1, 2, 8), (100, 2, 8), (100, 2, 3), (257, 4, 5)])
+def test_moe_combine_is_the_reference_accumulation(tokens, top_k, local, dtype):
+    """Bit-exact against the arithmetic of the reference's loop
+    (vllm/model_executor/models/mixtral_quant.py:141-151): each local expert's rows scaled by the
+    fp32 routing weight and rounded, added in ascending expert order with a rounding per add;
+    experts of other ranks contribute nothing."""
+    from vllm_legacy_amd import _custom_ops as ops
+    experts, hidden = 8, 1024
+    g = torch.Generator(device="cuda").manual_seed(tokens * top_k + local)
+    sel = torch.topk(torch.rand((tokens, experts), device="cuda", generator=g), top_k, dim=-1).indices
+    rw = torch.rand((tokens, top_k), device="cuda", generator=g)
+    rw = (rw / rw.sum(-1, keepdim=True)).contiguous()
+    lut = torch.full((experts, ), local, dtype=torch.int32)
+    lut[:local] = torch.arange(local, dtype=torch.int32)      # experts 0 .. local - 1 are ours
+    lut = lut.cuda()
+    offs, tok, pair_row, _ = ops.moe_sort_pairs(sel.contiguous(), lut, local + 1)
+    y = torch.empty((tokens * top_k, hidden), device="cuda").normal_(0, 1, generator=g).to(dtype)
+    # rows of the trailing bucket hold junk in the real block: the combine step must not read them
+    y[offs[local].item():] = float("nan")
+    got = ops.moe_combine(y, rw, sel.contiguous(), pair_row, lut, local)
+    pr = pair_row.view(tokens, top_k).long()
+    want = None
+    for e in range(local):
+        mask = sel == e                                                     # [T, top_k]
+        chosen = mask.any(-1)
+        rows = pr[torch.arange(tokens, device="cuda"), mask.long().argmax(-1)]
+        src = y[torch.where(chosen, rows, torch.zeros_like(rows))].clone()
+        src[~chosen] = 0                       # an expert's output for a token that skipped it: x 0
+        w = (rw * mask).sum(-1, keepdim=True)                               # fp32 [T, 1]
+        cur = (src.float() * w).to(dtype)
+        want = cur if want is None else (want.float() + cur.float()).to(dtype)
+    assert torch.equal(got.float(), want.float())
+
+
+@pytest.mark.parametrize("tokens", [24, 256, 1100])
+def test_grouped_block_equals_its_tensor_library_form(tokens):
+    """The block with the routing glue in two HIP launches and the gather folded into the first
+    product gives the bits of the same block written with argsort / index_select / index_add_;
+    256 tokens put 64 rows per expert on average, so tiles with one, two and three live 32-row
+    sub-tiles and row blocks that overflow a tile all occur."""
+    from vllm_legacy_amd.model.mixtral_moe import QuantMixtralMoE
+    moe = QuantMixtralMoE(512, 1024, 8, 2, "awq", 128, "cuda", seed=4)
+    for e in moe.experts:
+        for lin in (e.w13, e.w2):
+            lin.scales.data = (lin.scales.data.float() * 0.3).half()
+    g = torch.Generator(device="cuda").manual_seed(tokens)
+    x = torch.empty((tokens, 512), device="cuda").normal_(0, 1, generator=g).half()
+    with torch.inference_mode():
+        got = moe.forward_grouped(x)
+        rw, sel = moe.route(x)
+        want = moe._forward_grouped_torch(x, rw, sel.contiguous())
+    assert torch.equal(got.float(), want.float())
+
+
 @pytest.mark.parametrize("world,xgmi", [(2, False), (4, False), (2, True)])
 def test_moe_tensor_parallel_matches_single_rank(world, xgmi, tmp_path):
     """Experts split over ranks (np.array_split as in mixtral_quant.py:109-113), one all-reduce:

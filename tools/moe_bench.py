@@ -26,14 +26,21 @@ def timed(fn, iters=10):
 
 
 def main():
+    import argparse
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--tokens", default="16,64,256,1024,4096")
+    ap.add_argument("--grouped-only", action="store_true", help="profiling runs: the graph path alone")
+    a = ap.parse_args()
     moe = QuantMixtralMoE(4096, 14336, 8, 2, "awq", 128, "cuda", seed=0)
     res = []
-    for tokens in (16, 64, 256, 1024, 4096):
+    for tokens in [int(t) for t in a.tokens.split(",")]:
         x = torch.randn((tokens, 4096), device="cuda").half()
         with torch.inference_mode():
-            r = timed(lambda: moe.forward_routed(x))
-            d = timed(lambda: moe.forward_dense(x))
-            g = timed(lambda: moe.forward_grouped(x))
+            r = d = g = 0.0
+            if not a.grouped_only:
+                r = timed(lambda: moe.forward_routed(x))
+                d = timed(lambda: moe.forward_dense(x))
+                g = timed(lambda: moe.forward_grouped(x))
             # the grouped path has no host synchronisation: time it from a graph as decode runs it
             stream = torch.cuda.Stream()
             with torch.cuda.stream(stream):

@@ -495,28 +495,93 @@ def q4_gemm_packed(x: torch.Tensor, qweight: torch.Tensor, qzeros: torch.Tensor,
 
 def q4_gemm_grouped(x: torch.Tensor, qweight: torch.Tensor, qzeros: torch.Tensor,
                     scales: torch.Tensor, row_offsets: torch.Tensor, zero_offset: int,
-                    max_rows_per_set: Optional[int] = None) -> torch.Tensor:
+                    max_rows_per_set: Optional[int] = None,
+                    x_rows: Optional[torch.Tensor] = None,
+                    zero_outside: bool = True) -> torch.Tensor:
     """x [rows, k] fp16, rows sorted by weight set; qweight [sets, k/8, n], qzeros
-    [sets, k/group, n/8], scales [sets, k/group, n] (k-packed); row_offsets [sets + 1] int32 on
-    the device.  Returns [rows, n]; rows outside every set come back zero."""
+    [sets, k/group, n/8], scales [sets, k/group, n] (k-packed); row_offsets [>= sets + 1] int32 on
+    the device.  Returns [rows, n]; rows outside every set come back zero.
+    With x_rows (int32 [rows] on the device) product row r reads x[x_rows[r]] -- the gather of the
+    routed tokens without its copy.  With x_rows or zero_outside=False rows outside every set are
+    left unwritten (no fill of the output, no clearing of K-split slabs)."""
     _require_cuda(x, qweight, qzeros, scales, row_offsets)
     assert x.dtype == torch.float16 and scales.dtype == torch.float16
     assert row_offsets.dtype == torch.int32 and row_offsets.is_contiguous()
     assert qweight.is_contiguous() and qzeros.is_contiguous() and scales.is_contiguous()
     x = x.contiguous()
-    rows, k = x.shape
+    k = x.shape[1]
     sets, _, n = qweight.shape
-    assert row_offsets.numel() == sets + 1
+    assert row_offsets.numel() >= sets + 1
     group = k // qzeros.shape[1]
-    out = torch.zeros((rows, n), dtype=x.dtype, device=x.device)
     L = _lib.lib()
+    gather = x_rows is not None or not zero_outside
+    if x_rows is not None:
+        assert x_rows.dtype == torch.int32 and x_rows.is_contiguous() and x_rows.is_cuda
+        rows = x_rows.numel()
+    else:
+        rows = x.shape[0]
+    out = (torch.empty if gather else torch.zeros)((rows, n), dtype=x.dtype, device=x.device)
     ws_bytes = L.vla_q4_gemm_grouped_workspace_bytes(rows, n, k, group, sets)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device) if ws_bytes else None
+    bound = rows if max_rows_per_set is None else max_rows_per_set
     with torch.cuda.device(x.device):
-        check(L.vla_q4_gemm_grouped(
-            x.data_ptr(), qweight.data_ptr(), qzeros.data_ptr(), scales.data_ptr(), out.data_ptr(),
-            row_offsets.data_ptr(), sets, rows, rows if max_rows_per_set is None else max_rows_per_set,
-            n, k, group, zero_offset, _ptr(ws), ws_bytes, _stream(x.device)), "q4_gemm_grouped")
+        if gather:
+            check(L.vla_q4_gemm_grouped_gather(
+                x.data_ptr(), _ptr(x_rows), qweight.data_ptr(), qzeros.data_ptr(),
+                scales.data_ptr(), out.data_ptr(), row_offsets.data_ptr(), sets, rows, bound, n, k,
+                group, zero_offset, _ptr(ws), ws_bytes, _stream(x.device)), "q4_gemm_grouped_gather")
+        else:
+            check(L.vla_q4_gemm_grouped(
+                x.data_ptr(), qweight.data_ptr(), qzeros.data_ptr(), scales.data_ptr(),
+                out.data_ptr(), row_offsets.data_ptr(), sets, rows, bound, n, k, group, zero_offset,
+                _ptr(ws), ws_bytes, _stream(x.device)), "q4_gemm_grouped")
+    return out
+
+
+def moe_sort_pairs(selected_experts: torch.Tensor, bucket_of: torch.Tensor, num_buckets: int,
+                   want_row_bucket: bool = False):
+    """Stable bucketing of the (token, choice) pairs of a top-k routing by local expert, on the
+    device.  selected_experts int64 [tokens, top_k]; bucket_of int32 [experts] (the trailing bucket
+    num_buckets - 1 takes the experts of other ranks).  Returns (row_offsets int32
+    [num_buckets + 1], sorted_token int32 [pairs], pair_row int32 [pairs], row_bucket int32 [pairs]
+    or None).  Raises when the batch is too large for the one-workgroup sort."""
+    _require_cuda(selected_experts, bucket_of)
+    assert selected_experts.dtype == torch.int64 and selected_experts.is_contiguous()
+    assert bucket_of.dtype == torch.int32 and bucket_of.is_contiguous()
+    tokens, top_k = selected_experts.shape
+    dev = selected_experts.device
+    pairs = tokens * top_k
+    row_offsets = torch.empty(num_buckets + 1, dtype=torch.int32, device=dev)
+    sorted_token = torch.empty(pairs, dtype=torch.int32, device=dev)
+    pair_row = torch.empty(pairs, dtype=torch.int32, device=dev)
+    row_bucket = torch.empty(pairs, dtype=torch.int32, device=dev) if want_row_bucket else None
+    with torch.cuda.device(dev):
+        check(_lib.lib().vla_moe_sort_pairs(
+            selected_experts.data_ptr(), bucket_of.data_ptr(), bucket_of.numel(), tokens, top_k,
+            num_buckets, row_offsets.data_ptr(), sorted_token.data_ptr(), pair_row.data_ptr(),
+            _ptr(row_bucket), _stream(dev)), "moe_sort_pairs")
+    return row_offsets, sorted_token, pair_row, row_bucket
+
+
+MOE_SORT_MAX_COUNTERS = 15 * 1024   # segments of 64 pairs x buckets the one-workgroup sort holds
+
+
+def moe_combine(y: torch.Tensor, routing_weights: torch.Tensor, selected_experts: torch.Tensor,
+                pair_row: torch.Tensor, bucket_of: torch.Tensor, num_local: int) -> torch.Tensor:
+    """out[t] = sum over token t's local experts (ascending expert index) of
+    model_dtype(y[pair_row[t, e]] * weight[t, e]), partial sums rounded to the model dtype."""
+    _require_cuda(y, routing_weights, selected_experts, pair_row, bucket_of)
+    assert routing_weights.dtype == torch.float32 and routing_weights.is_contiguous()
+    assert selected_experts.dtype == torch.int64 and selected_experts.is_contiguous()
+    assert y.is_contiguous() and pair_row.dtype == torch.int32 and pair_row.is_contiguous()
+    tokens, top_k = selected_experts.shape
+    hidden = y.shape[1]
+    out = torch.empty((tokens, hidden), dtype=y.dtype, device=y.device)
+    with torch.cuda.device(y.device):
+        check(_lib.lib().vla_moe_combine(
+            y.data_ptr(), routing_weights.data_ptr(), selected_experts.data_ptr(),
+            pair_row.data_ptr(), bucket_of.data_ptr(), bucket_of.numel(), num_local, tokens, top_k,
+            hidden, out.data_ptr(), _dt(y), _stream(y.device)), "moe_combine")
     return out
 
 

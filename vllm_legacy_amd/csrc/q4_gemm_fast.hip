@@ -236,9 +236,13 @@ __device__ __forceinline__ void store_tile(const f32x16 (&acc)[MT], void* __rest
 // GROUPED (several weight sets in one launch, e.g. the experts of an MoE block): x and out hold
 // the row blocks of all sets back to back, gp.row_offsets[e] .. [e + 1] on the device says which
 // rows belong to set e, blockIdx.y = e * tiles_per_set + row tile, and a workgroup whose tile
-// lies past its set's rows leaves at once.
+// lies past its set's rows leaves at once.  (Skipping the empty 32-row sub-tiles of a partly
+// filled tile behind wave-uniform branches was measured and dropped: the branches around the
+// fragment reads and MFMAs cost the schedule more than the skipped work saves, 227 + 115 ->
+// 257 + 136 us for the two launches of a Mixtral-8x7B block at 256 tokens.)
 struct Q4Groups {
   const int* row_offsets;      // [num_sets + 1]
+  const int* x_rows;           // null, or [total_rows]: row r of the product reads x[x_rows[r]]
   int tiles_per_set;
   int total_rows;              // rows of x / out, the slab pitch of a split product
   int64_t w_stride, z_stride, s_stride;   // elements between consecutive sets
@@ -278,7 +282,7 @@ __global__ __launch_bounds__(64 * NW * KW) void q4_gemm_m32_kernel(
     m = gp.row_offsets[set + 1] - row_base;
     slab_rows = gp.total_rows;
     if (tile_y * TMW >= m) return;
-    x += (int64_t)row_base * k;
+    if (!gp.x_rows) x += (int64_t)row_base * k;
     qw += (int64_t)set * gp.w_stride;
     qz += (int64_t)set * gp.z_stride;
     scales += (int64_t)set * gp.s_stride;
@@ -300,8 +304,13 @@ __global__ __launch_bounds__(64 * NW * KW) void q4_gemm_m32_kernel(
   const int srow = tid >> 3, schunk = tid & 7;
   const _Float16* xsrc[XCH];
 #pragma unroll
-  for (int i = 0; i < XCH; ++i)
-    xsrc[i] = x + (int64_t)min(m0 + srow + XROWS * i, m - 1) * k + 8 * schunk;
+  for (int i = 0; i < XCH; ++i) {
+    int r = min(m0 + srow + XROWS * i, m - 1);
+    if constexpr (GROUPED) {
+      if (gp.x_rows) r = gp.x_rows[row_base + r];
+    }
+    xsrc[i] = x + (int64_t)r * k + 8 * schunk;
+  }
   struct XSet { u32x4 v[XCH]; };
   auto load_x = [&](int step, XSet& d) {
     const int k0 = k_begin + phys(step) * TK;
@@ -1546,11 +1555,15 @@ extern "C" int64_t vla_q4_gemm_grouped_workspace_bytes(int total_rows, int n, in
   return want > 1 ? (int64_t)want * total_rows * n * 4 : 0;
 }
 
-extern "C" int vla_q4_gemm_grouped(const void* x, const int32_t* qweight, const int32_t* qzeros,
-                                   const void* scales, void* out, const int* row_offsets,
-                                   int num_sets, int total_rows, int max_rows_per_set, int n, int k,
-                                   int group, int zero_offset, void* workspace,
-                                   int64_t workspace_bytes, void* stream) {
+// x_rows: null, or the row of x each product row reads (the gather of the routed tokens folded
+// into the tile staging).  clear_slabs: rows outside every set come back zero from a K-split
+// launch; a caller that never reads such rows can spare the memset.
+static int q4_gemm_grouped_run(const void* x, const int* x_rows, const int32_t* qweight,
+                               const int32_t* qzeros, const void* scales, void* out,
+                               const int* row_offsets, int num_sets, int total_rows,
+                               int max_rows_per_set, int n, int k, int group, int zero_offset,
+                               void* workspace, int64_t workspace_bytes, bool clear_slabs,
+                               void* stream) {
   (void)hipGetLastError();
   if (!x || !qweight || !qzeros || !scales || !out || !row_offsets || num_sets <= 0 ||
       total_rows < 0 || max_rows_per_set < 0)
@@ -1567,10 +1580,15 @@ extern "C" int vla_q4_gemm_grouped(const void* x, const int32_t* qweight, const 
     splits = 1;
   Q4Groups gp{};
   gp.row_offsets = row_offsets;
+  gp.x_rows = x_rows;
   // 64-row tiles for decode-sized sets, 128-row tiles once the average set fills them
   // (measured on Mixtral shapes: 256 rows per set 1.25 ms with 64-row tiles, 1.31 with 128-row
-  // ones; 1024 rows per set 4.26 against 3.99)
-  const int mt = total_rows / num_sets >= 384 ? 4 : 2;
+  // ones; 1024 rows per set 4.26 against 3.99).  VLA_Q4_GROUPED_MT=2/4 overrides (kernel studies).
+  int mt = total_rows / num_sets >= 384 ? 4 : 2;
+  if (const char* e = getenv("VLA_Q4_GROUPED_MT")) {
+    const int v = atoi(e);
+    if (v == 2 || v == 4) mt = v;
+  }
   gp.tiles_per_set = (max_rows_per_set + 32 * mt - 1) / (32 * mt);
   gp.total_rows = total_rows;
   gp.w_stride = (int64_t)(k / 8) * n;
@@ -1589,8 +1607,8 @@ extern "C" int vla_q4_gemm_grouped(const void* x, const int32_t* qweight, const 
   const int kw = (kw_enabled && mt == 2 && total_rows <= 32 * num_sets &&
                   kps % (2 * part_unit) == 0 && kps / (2 * TK) >= 8) ? 2 : 1;
   void* dst = splits > 1 ? workspace : out;
-  if (splits > 1) {
-    // rows of sets that got fewer rows than a tile are never written: the sum must not see junk
+  if (splits > 1 && clear_slabs) {
+    // rows that belong to no set are never written: their sums must not be junk
     VLA_HIP_CHECK(hipMemsetAsync(workspace, 0, (size_t)need, s));
   }
 #define VLA_Q4G_ARGS                                                                            \
@@ -1629,3 +1647,25 @@ extern "C" int vla_q4_gemm_grouped(const void* x, const int32_t* qweight, const 
   }
   return VLA_OK;
 }
+
+extern "C" int vla_q4_gemm_grouped(const void* x, const int32_t* qweight, const int32_t* qzeros,
+                                   const void* scales, void* out, const int* row_offsets,
+                                   int num_sets, int total_rows, int max_rows_per_set, int n, int k,
+                                   int group, int zero_offset, void* workspace,
+                                   int64_t workspace_bytes, void* stream) {
+  return q4_gemm_grouped_run(x, nullptr, qweight, qzeros, scales, out, row_offsets, num_sets,
+                             total_rows, max_rows_per_set, n, k, group, zero_offset, workspace,
+                             workspace_bytes, true, stream);
+}
+
+extern "C" int vla_q4_gemm_grouped_gather(const void* x, const int* x_rows, const int32_t* qweight,
+                                          const int32_t* qzeros, const void* scales, void* out,
+                                          const int* row_offsets, int num_sets, int total_rows,
+                                          int max_rows_per_set, int n, int k, int group,
+                                          int zero_offset, void* workspace,
+                                          int64_t workspace_bytes, void* stream) {
+  return q4_gemm_grouped_run(x, x_rows, qweight, qzeros, scales, out, row_offsets, num_sets,
+                             total_rows, max_rows_per_set, n, k, group, zero_offset, workspace,
+                             workspace_bytes, false, stream);
+}
+

@@ -142,16 +142,50 @@ class QuantMixtralMoE(nn.Module):
             for li, idx in enumerate(self.expert_indicies):
                 lut[idx] = li
             self._local_of = lut.to(self.gate.device)
+            self._bucket_of = self._local_of.to(torch.int32).contiguous()
         return st
 
     def forward_grouped(self, hidden_states: torch.Tensor) -> torch.Tensor:
         """The (token, expert) pairs are sorted by expert on the device and
         every local expert's rows go through ONE grouped GEMM launch per projection -- no host
-        synchronisation (graph-capturable) and no work on tokens an expert was not chosen for."""
+        synchronisation (graph-capturable) and no work on tokens an expert was not chosen for.
+        After the router's top-k the block is five launches: pair sort, w13 (reading each row's
+        token through the sort's index, so the gathered copy of the activations never exists),
+        SiLU * mul, w2, and the weighted sum per token."""
         num_tokens, hidden_dim = hidden_states.shape
         (w13, w2) = self._stacked()
         n_local = len(self.expert_indicies)
         routing_weights, selected_experts = self.route(hidden_states)
+        selected_experts = selected_experts.contiguous()
+        act_order = w13[3] is not None
+        pairs = num_tokens * self.top_k
+        if ((pairs + 63) // 64) * (n_local + 1) > ops.MOE_SORT_MAX_COUNTERS:
+            return self._forward_grouped_torch(hidden_states, routing_weights, selected_experts)
+        offsets, sorted_token, pair_row, row_bucket = ops.moe_sort_pairs(
+            selected_experts, self._bucket_of, n_local + 1, want_row_bucket=act_order)
+        zo = self._zero_offset
+        if act_order:       # act-ordered experts: each row's columns in its expert's order
+            xs = hidden_states.index_select(0, sorted_token)
+            xs = torch.gather(xs, 1, w13[3][row_bucket.long()])
+            h = ops.q4_gemm_grouped(xs, w13[0], w13[1], w13[2], offsets, zo, pairs)
+        else:
+            h = ops.q4_gemm_grouped(hidden_states, w13[0], w13[1], w13[2], offsets, zo, pairs,
+                                    x_rows=sorted_token)
+        h = self.experts[self.expert_indicies[0]].act_fn(h)
+        if act_order:
+            h = torch.gather(h, 1, w2[3][row_bucket.long()])
+        # rows of other ranks' experts (the trailing bucket) are never read by the combine step
+        y = ops.q4_gemm_grouped(h, w2[0], w2[1], w2[2], offsets, zo, pairs, zero_outside=False)
+        final = ops.moe_combine(y, routing_weights.contiguous(), selected_experts, pair_row,
+                                self._bucket_of, n_local)
+        return tensor_model_parallel_all_reduce(final).view(num_tokens, hidden_dim)
+
+    def _forward_grouped_torch(self, hidden_states, routing_weights, selected_experts):
+        """forward_grouped with the routing glue as tensor operations (batches beyond the
+        one-workgroup pair sort)."""
+        num_tokens, hidden_dim = hidden_states.shape
+        (w13, w2) = self._stacked()
+        n_local = len(self.expert_indicies)
         local = self._local_of[selected_experts.reshape(-1)]             # [T * top_k]
         order = torch.argsort(local, stable=True)
         # (bincount would synchronise to size its result)
@@ -170,7 +204,9 @@ class QuantMixtralMoE(nn.Module):
         if w2[3] is not None:
             h = torch.gather(h, 1, w2[3][row_expert])
         y = ops.q4_gemm_grouped(h, w2[0], w2[1], w2[2], offsets, zo, rows)
-        y.mul_(routing_weights.reshape(-1)[order].unsqueeze(1))           # fp32 product, fp16 store
+        # fp32 product, then the rounding to the model dtype, as two steps: written as one
+        # in-place mixed multiply the compiler may fuse them into a single rounding
+        y = (y.float() * routing_weights.reshape(-1)[order].unsqueeze(1)).to(y.dtype)
         final = torch.zeros_like(hidden_states)
         final.index_add_(0, token, y)      # rows of other ranks' experts are zero
         return tensor_model_parallel_all_reduce(final).view(num_tokens, hidden_dim)
