@@ -254,19 +254,27 @@ struct Q4Groups {
 // of issue work behind a few hundred cycles of load and MFMA-chain latency, so what a small-batch
 // launch lacks is waves per SIMD -- and more K slices across workgroups would pay for them with
 // fp32 slabs in HBM.
-template <int ZOFF, bool SPLIT, int NW, int MT, bool GROUPED = false, bool G2 = false, int KW = 1>
-__global__ __launch_bounds__(64 * NW * KW) void q4_gemm_m32_kernel(
+// LV: how many of the tile's MT 32-row sub-tiles hold rows.  It is MT everywhere except in a
+// grouped launch, where a set's share of a decode batch rarely fills its tile: the kernel looks
+// the row count up and runs the body built for that many live sub-tiles, which spends no x load,
+// no fragment read and no MFMA on the empty ones.  (The same skip as wave-uniform branches inside
+// one body was measured first: it pays at 16-64 tokens per block but costs full tiles their
+// schedule, Mixtral-8x7B block at 256 tokens 0.425 -> 0.46 ms.)
+template <int ZOFF, bool SPLIT, int NW, int MT, bool GROUPED, bool G2, int KW, int LV>
+__device__ __forceinline__ void q4_gemm_m32_body(
     const _Float16* __restrict__ x, const uint32_t* __restrict__ qw,
     const uint32_t* __restrict__ qz, const _Float16* __restrict__ scales, void* __restrict__ outp,
-    int m, int n, int k, int group_size, int k_per_split, Q4Groups gp = Q4Groups{}) {
+    int m, int n, int k, int group_size, int k_per_split, const Q4Groups& gp,
+    unsigned char* __restrict__ xs_all) {
   constexpr int THREADS = 64 * NW;               // threads of one K part
   constexpr int TMW = 32 * MT;                   // rows per workgroup
   constexpr int X2_TILE_BYTES = TMW * TK * 2;    // one LDS buffer: 16 KiB at MT = 4
   static_assert((TMW * 8) % THREADS == 0, "x staging covers the tile in whole passes");
   static_assert(KW == 1 || (NW <= 4 && (KW == 2 || KW == 4)), "LDS reduction fits the x buffers");
-  constexpr int XCH = (TMW * 8) / THREADS;  // 16-byte chunks of the x tile per thread
+  static_assert(LV >= 1 && LV <= MT, "live sub-tiles");
   constexpr int XROWS = THREADS / 8;        // rows covered by one pass of the staging threads
-  __shared__ __attribute__((aligned(16))) unsigned char xs_all[KW * 2 * X2_TILE_BYTES];
+  // 16-byte chunks of the x tile per thread: the staging passes that reach a live sub-tile
+  constexpr int XCH = (32 * LV + XROWS - 1) / XROWS;
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -368,10 +376,10 @@ __global__ __launch_bounds__(64 * NW * KW) void q4_gemm_m32_kernel(
 
   // a single 32-row tile would chain all four MFMAs of a step on one accumulator (each waits for
   // the one before): odd slices get a second one there
-  constexpr bool DUAL = MT == 1;
-  f32x16 acc[MT], acc_odd[DUAL ? 1 : MT];
+  constexpr bool DUAL = LV == 1;
+  f32x16 acc[LV], acc_odd[1];
 #pragma unroll
-  for (int a = 0; a < MT; ++a)
+  for (int a = 0; a < LV; ++a)
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[a][i] = 0.f;
   if constexpr (DUAL) {
@@ -418,9 +426,9 @@ __global__ __launch_bounds__(64 * NW * KW) void q4_gemm_m32_kernel(
     const f16x2 sc2 = as_h2(__builtin_amdgcn_perm(zs.s, zs.s, ssel));
 
     const unsigned char* xb = xs + buf * X2_TILE_BYTES;
-    auto read_a = [&](int s, u32x4 (&af)[MT]) {
+    auto read_a = [&](int s, u32x4 (&af)[LV]) {
 #pragma unroll
-      for (int a = 0; a < MT; ++a) {
+      for (int a = 0; a < LV; ++a) {
         const int row = 32 * a + c;
         af[a] = *reinterpret_cast<const u32x4*>(
             xb + row * 128 + (((2 * s + h) ^ ((row >> 1) & 7)) << 4));
@@ -439,14 +447,14 @@ __global__ __launch_bounds__(64 * NW * KW) void q4_gemm_m32_kernel(
       bf[3] = as_u32(d3 * sc2);
       return bf;
     };
-    auto mma = [&](const u32x4 (&af)[MT], const u32x4& bf) {
+    auto mma = [&](const u32x4 (&af)[LV], const u32x4& bf) {
 #pragma unroll
-      for (int a = 0; a < MT; ++a)
+      for (int a = 0; a < LV; ++a)
         acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, bf),
                                                         __builtin_bit_cast(f16x8, af[a]), acc[a], 0,
                                                         0, 0);
     };
-    auto mma_odd = [&](const u32x4 (&af)[MT], const u32x4& bf) {
+    auto mma_odd = [&](const u32x4 (&af)[LV], const u32x4& bf) {
       if constexpr (DUAL)
         acc_odd[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, bf),
                                                             __builtin_bit_cast(f16x8, af[0]),
@@ -456,7 +464,7 @@ __global__ __launch_bounds__(64 * NW * KW) void q4_gemm_m32_kernel(
     };
     // fragments of slice s+1 are requested before the MFMAs of slice s are issued
 #define VLA_SB __builtin_amdgcn_sched_barrier(0)
-    u32x4 fa[MT], fb[MT];
+    u32x4 fa[LV], fb[LV];
     read_a(0, fa);
     u32x4 b0 = dequant(0);
     VLA_SB;
@@ -538,21 +546,21 @@ __global__ __launch_bounds__(64 * NW * KW) void q4_gemm_m32_kernel(
   // [0, stride) through LDS (the x buffers, free after the last step's barrier), stride = KW/2 .. 1
   if constexpr (KW > 1) {
     float* red = reinterpret_cast<float*>(xs_all);
-    constexpr int SLOT = NW * MT * 16 * 64;        // floats one part hands over
+    constexpr int SLOT = NW * LV * 16 * 64;        // floats one part hands over
 #pragma unroll
     for (int stride = KW / 2; stride >= 1; stride >>= 1) {
       if (wk >= stride && wk < 2 * stride) {
-        float* dst = red + (wk - stride) * SLOT + wn * (MT * 16 * 64) + lane;
+        float* dst = red + (wk - stride) * SLOT + wn * (LV * 16 * 64) + lane;
 #pragma unroll
-        for (int a = 0; a < MT; ++a)
+        for (int a = 0; a < LV; ++a)
 #pragma unroll
           for (int i = 0; i < 16; ++i) dst[(a * 16 + i) * 64] = acc[a][i];
       }
       __syncthreads();
       if (wk < stride) {
-        const float* src = red + wk * SLOT + wn * (MT * 16 * 64) + lane;
+        const float* src = red + wk * SLOT + wn * (LV * 16 * 64) + lane;
 #pragma unroll
-        for (int a = 0; a < MT; ++a)
+        for (int a = 0; a < LV; ++a)
 #pragma unroll
           for (int i = 0; i < 16; ++i) acc[a][i] += src[(a * 16 + i) * 64];
       }
@@ -564,7 +572,7 @@ __global__ __launch_bounds__(64 * NW * KW) void q4_gemm_m32_kernel(
   // out transposed: lane (h, c) holds row 32 a + c of x and, in registers 4 j .. 4 j + 3, the four
   // adjacent columns 8 j + 4 h .. + 3 of the wave's 32 -- one 8- or 16-byte store per quad instead
   // of four 2- or 4-byte ones (the store tail of a 128-row tile was a sixth of the kernel).
-  store_tile<SPLIT, MT>(acc, outp, m0 + c, m, n0 + 32 * wn + 4 * h, n,
+  store_tile<SPLIT, LV>(acc, outp, m0 + c, m, n0 + 32 * wn + 4 * h, n,
                         SPLIT ? (int64_t)blockIdx.z * slab_rows + row_base : (int64_t)row_base);
 #ifdef VLA_Q4_STAMP
   {
@@ -577,6 +585,34 @@ __global__ __launch_bounds__(64 * NW * KW) void q4_gemm_m32_kernel(
              (unsigned long long)(st_end - st_entry));
   }
 #endif
+}
+
+template <int ZOFF, bool SPLIT, int NW, int MT, bool GROUPED = false, bool G2 = false, int KW = 1>
+__global__ __launch_bounds__(64 * NW * KW) void q4_gemm_m32_kernel(
+    const _Float16* __restrict__ x, const uint32_t* __restrict__ qw,
+    const uint32_t* __restrict__ qz, const _Float16* __restrict__ scales, void* __restrict__ outp,
+    int m, int n, int k, int group_size, int k_per_split, Q4Groups gp = Q4Groups{}) {
+  __shared__ __attribute__((aligned(16))) unsigned char xs_all[KW * 2 * (32 * MT) * TK * 2];
+#define VLA_Q4_BODY(LV_)                                                                          \
+  q4_gemm_m32_body<ZOFF, SPLIT, NW, MT, GROUPED, G2, KW, LV_>(x, qw, qz, scales, outp, m, n, k,    \
+                                                              group_size, k_per_split, gp, xs_all)
+  if constexpr (!GROUPED) {
+    VLA_Q4_BODY(MT);
+  } else {
+    const int set = blockIdx.y / gp.tiles_per_set, tile_y = blockIdx.y % gp.tiles_per_set;
+    const int rows = gp.row_offsets[set + 1] - gp.row_offsets[set] - tile_y * (32 * MT);
+    if (rows <= 0) return;
+    const int live = __builtin_amdgcn_readfirstlane((rows + 31) >> 5);
+    if constexpr (MT >= 4) {
+      if (live >= 4) { VLA_Q4_BODY(MT >= 4 ? 4 : MT); return; }
+      if (live == 3) { VLA_Q4_BODY(MT >= 4 ? 3 : MT); return; }
+    }
+    if constexpr (MT >= 2) {
+      if (live >= 2) { VLA_Q4_BODY(MT >= 2 ? 2 : MT); return; }
+    }
+    VLA_Q4_BODY(1);
+  }
+#undef VLA_Q4_BODY
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1581,10 +1617,14 @@ static int q4_gemm_grouped_run(const void* x, const int* x_rows, const int32_t* 
   Q4Groups gp{};
   gp.row_offsets = row_offsets;
   gp.x_rows = x_rows;
-  // 64-row tiles for decode-sized sets, 128-row tiles once the average set fills them
-  // (measured on Mixtral shapes: 256 rows per set 1.25 ms with 64-row tiles, 1.31 with 128-row
-  // ones; 1024 rows per set 4.26 against 3.99).  VLA_Q4_GROUPED_MT=2/4 overrides (kernel studies).
-  int mt = total_rows / num_sets >= 384 ? 4 : 2;
+  // Tile height.  A workgroup runs the body built for its tile's live 32-row sub-tiles, so a
+  // tall tile costs a short row block registers, not MFMAs, while a short tile costs a row block
+  // that overflows it a second pass over the set's weights -- and routing spreads rows unevenly
+  // (top-2 of 8 over 256 tokens: 64 rows per expert on average, half of the experts above that).
+  // Mixtral-8x7B block from a graph, 64- against 128-row tiles: 64 tokens 0.258 / 0.266 ms, 256
+  // tokens 0.409 / 0.377, 1024 tokens 1.04 / 0.98 (96 tokens 0.280 / 0.269): 128-row tiles from 24 rows per set on average.
+  // VLA_Q4_GROUPED_MT=2/4 overrides (kernel studies).
+  int mt = total_rows / num_sets >= 24 ? 4 : 2;
   if (const char* e = getenv("VLA_Q4_GROUPED_MT")) {
     const int v = atoi(e);
     if (v == 2 || v == 4) mt = v;
