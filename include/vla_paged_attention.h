@@ -328,6 +328,10 @@ int vla_q4_gemm_grouped_gather(const void* x, const int* x_rows, const int32_t* 
 
 /* Routing glue of the quantized Mixtral block (vllm/model_executor/models/mixtral_quant.py:129-156)
  * around the two grouped products, on the device and without host synchronisation.
+ * vla_moe_route_topk: router_logits [num_tokens, num_experts] (the gate's output, :130-131) ->
+ * routing_weights fp32 [num_tokens, top_k] = softmax in fp32, the top_k largest (on equal values
+ * the lower expert index), divided by their sum (:132-138), and selected_experts int64 of the
+ * same shape, choices in descending weight.  num_experts <= 64.
  * vla_moe_sort_pairs: selected_experts int64 [num_tokens * top_k] (torch.topk's indices, :136-137);
  * bucket_of int32 [num_experts] maps an expert to its bucket: 0 .. num_buckets - 2 for the experts
  * this rank holds (:109-123), num_buckets - 1 for all others.  Writes row_offsets
@@ -340,6 +344,8 @@ int vla_q4_gemm_grouped_gather(const void* x, const int* x_rows, const int32_t* 
  * model dtype: `expert_layer(hidden_states).mul_(expert_weights)` and `final.add_(...)` of
  * :141-151, where the experts a token did not choose add exact zeros.  y [pairs, hidden] fp16 /
  * bf16, routing_weights fp32 [num_tokens * top_k], top_k <= 8, hidden a multiple of 8. */
+int vla_moe_route_topk(const void* router_logits, int num_tokens, int num_experts, int top_k,
+                       float* routing_weights, int64_t* selected_experts, int dtype, void* stream);
 int vla_moe_sort_pairs(const int64_t* selected_experts, const int* bucket_of, int num_experts,
                        int num_tokens, int top_k, int num_buckets, int* row_offsets,
                        int* sorted_token, int* pair_row, int* row_bucket, void* stream);

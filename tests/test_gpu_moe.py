@@ -67,6 +67,31 @@ def test_routed_moe_matches_dense_loop_and_oracle(tokens):
     np.testing.assert_allclose(routed.float().cpu().numpy(), want, rtol=1e-2, atol=1e-2)
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("tokens,experts,top_k", [(1, 8, 2), (257, 8, 2), (1000, 8, 2), (300, 64, 4),
+                                                  (64, 8, 1), (50, 3, 3)])
+def test_moe_route_topk_is_softmax_topk_renormalise(tokens, experts, top_k, dtype):
+    """The one-launch router against the reference's three steps
+    (vllm/model_executor/models/mixtral_quant.py:131-138): fp32 softmax, top-k, division by the
+    sum of the chosen weights.  Logits are drawn on a coarse grid so that equal values are common,
+    also across the k-th / (k+1)-th place, where the choice decides which expert runs: the same
+    experts must come out (a top-k keeps the lower index among equals), and the same weights."""
+    from vllm_legacy_amd import _custom_ops as ops
+    g = torch.Generator(device="cuda").manual_seed(tokens + experts)
+    logits = (torch.randint(-12, 13, (tokens, experts), device="cuda", generator=g).float() / 4).to(dtype)
+    w, sel = ops.moe_route_topk(logits, top_k)
+    p = torch.softmax(logits, dim=1, dtype=torch.float)
+    tw, tsel = torch.topk(p, top_k, dim=-1)
+    tw = tw / tw.sum(dim=-1, keepdim=True)
+    # the chosen set, and the weight each chosen expert got (the order among equal weights is
+    # the sort's business and changes nothing downstream)
+    assert torch.equal(sel.sort(-1).values, tsel.sort(-1).values)
+    dense = torch.zeros((tokens, experts), device="cuda").scatter_(1, sel, w)
+    tdense = torch.zeros((tokens, experts), device="cuda").scatter_(1, tsel, tw)
+    torch.testing.assert_close(dense, tdense, rtol=2e-7, atol=0)
+    assert torch.all(w[:, :-1] >= w[:, 1:]) if top_k > 1 else True
+
+
 @pytest.mark.parametrize("tokens,top_k,experts,local", [(1, 2, 8, 8), (37, 2, 8, 8), (256, 2, 8, 4),
                                                         (1000, 2, 8, 8), (4096, 2, 8, 8),
                                                         (300, 4, 64, 16), (64, 1, 8, 2)])

@@ -538,6 +538,21 @@ def q4_gemm_grouped(x: torch.Tensor, qweight: torch.Tensor, qzeros: torch.Tensor
     return out
 
 
+def moe_route_topk(router_logits: torch.Tensor, top_k: int):
+    """softmax(router_logits, fp32) -> top_k -> renormalise, one launch.  Returns (routing_weights
+    fp32 [tokens, top_k], selected_experts int64 [tokens, top_k]); at most 64 experts."""
+    _require_cuda(router_logits)
+    router_logits = router_logits.contiguous()
+    tokens, experts = router_logits.shape
+    w = torch.empty((tokens, top_k), dtype=torch.float32, device=router_logits.device)
+    sel = torch.empty((tokens, top_k), dtype=torch.int64, device=router_logits.device)
+    with torch.cuda.device(router_logits.device):
+        check(_lib.lib().vla_moe_route_topk(
+            router_logits.data_ptr(), tokens, experts, top_k, w.data_ptr(), sel.data_ptr(),
+            _dt(router_logits), _stream(router_logits.device)), "moe_route_topk")
+    return w, sel
+
+
 def moe_sort_pairs(selected_experts: torch.Tensor, bucket_of: torch.Tensor, num_buckets: int,
                    want_row_bucket: bool = False):
     """Stable bucketing of the (token, choice) pairs of a top-k routing by local expert, on the

@@ -2,6 +2,7 @@
 // the grouped int4 GEMMs, and between the second GEMM and the block's output
 // (vllm/model_executor/models/mixtral_quant.py:129-156).
 //
+//   moe_route_topk   softmax of the router logits in fp32, top-k, renormalisation (:131-138)
 //   moe_sort_pairs   the (token, choice) pairs, bucketed by local expert, in pair order inside a
 //                    bucket (a stable counting sort): per-bucket row offsets for the grouped launch,
 //                    the token each sorted row reads, and where every pair went
@@ -80,6 +81,42 @@ __global__ __launch_bounds__(kSortThreads) void moe_sort_pairs_kernel(
   }
 }
 
+// One wave per token, expert e on lane e.  Softmax as a tensor library's warp softmax evaluates
+// it (fp32: exp(x - max) / sum, the sum as an xor tree over the lanes), then k rounds of "largest
+// remaining value, lowest index among equals" -- the choice a radix-select top-k makes when values
+// tie at the boundary -- and the division by the sum of the chosen weights.
+template <class S>
+__global__ __launch_bounds__(256) void moe_route_topk_kernel(
+    const typename S::T* __restrict__ logits, int num_tokens, int num_experts, int top_k,
+    float* __restrict__ weights, int64_t* __restrict__ experts) {
+  const int lane = threadIdx.x & 63;
+  const int tok = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (tok >= num_tokens) return;
+  const bool has = lane < num_experts;
+  const float x = has ? S::to_f32(logits[(int64_t)tok * num_experts + lane]) : -INFINITY;
+  const float mx = wave_max(x);
+  const float e = has ? expf(x - mx) : 0.f;
+  const float p = e / wave_sum(e);
+  float v = has ? p : -INFINITY;
+  float chosen_w = 0.f, total = 0.f;    // lane j keeps the j-th choice
+  int chosen_e = 0;
+  for (int j = 0; j < top_k; ++j) {
+    const float best = wave_max(v);
+    const uint64_t at = __ballot(v == best);
+    const int idx = __ffsll((unsigned long long)at) - 1;
+    if (lane == j) {
+      chosen_w = best;
+      chosen_e = idx;
+    }
+    total += best;                      // summed in choice order, like a sum over the last dim
+    if (lane == idx) v = -INFINITY;
+  }
+  if (lane < top_k) {
+    weights[(int64_t)tok * top_k + lane] = chosen_w / total;
+    experts[(int64_t)tok * top_k + lane] = chosen_e;
+  }
+}
+
 // One workgroup per token; 8 elements (16 bytes) per lane and pass.
 template <class S, int MAXK>
 __global__ __launch_bounds__(256) void moe_combine_kernel(
@@ -151,6 +188,34 @@ __global__ __launch_bounds__(256) void moe_combine_kernel(
 }  // namespace vla
 
 using namespace vla;
+
+extern "C" int vla_moe_route_topk(const void* router_logits, int num_tokens, int num_experts,
+                                  int top_k, float* routing_weights, int64_t* selected_experts,
+                                  int dtype, void* stream) {
+  (void)hipGetLastError();
+  if (num_tokens == 0) return VLA_OK;
+  if (!router_logits || !routing_weights || !selected_experts || num_tokens < 0 ||
+      num_experts <= 0 || num_experts > 64 || top_k <= 0 || top_k > num_experts || top_k > 64)
+    return VLA_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  const dim3 grid((num_tokens + 3) / 4);
+  if (dtype == VLA_F16)
+    hipLaunchKernelGGL((moe_route_topk_kernel<F16>), grid, dim3(256), 0, s,
+                       (const _Float16*)router_logits, num_tokens, num_experts, top_k,
+                       routing_weights, selected_experts);
+  else if (dtype == VLA_BF16)
+    hipLaunchKernelGGL((moe_route_topk_kernel<BF16>), grid, dim3(256), 0, s,
+                       (const __bf16*)router_logits, num_tokens, num_experts, top_k,
+                       routing_weights, selected_experts);
+  else if (dtype == VLA_F32)
+    hipLaunchKernelGGL((moe_route_topk_kernel<F32>), grid, dim3(256), 0, s,
+                       (const float*)router_logits, num_tokens, num_experts, top_k,
+                       routing_weights, selected_experts);
+  else
+    return VLA_ERR_DTYPE;
+  VLA_HIP_CHECK(hipGetLastError());
+  return VLA_OK;
+}
 
 extern "C" int vla_moe_sort_pairs(const int64_t* selected_experts, const int* bucket_of,
                                   int num_experts, int num_tokens, int top_k, int num_buckets,

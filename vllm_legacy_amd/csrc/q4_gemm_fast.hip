@@ -24,6 +24,22 @@
 
 #include "vla_common.h"
 
+// Register-ring depths of the small-batch and grouped launches (kernel studies,
+// tools/exp/build_ring.sh): deeper rings were measured and lose everywhere -- weight words 7
+// steps ahead instead of 3: layer GEMMs at batch 16 58.5 -> 64.0 us, at batch 64 85.3 -> 121.8
+// (the 1024-thread launches spill), Mixtral block unchanged within 2 %; x 8 steps ahead on top:
+// 69.1 / 131.2.  Loads retire in order, so a wave can use x(t + 4) only after every older weight
+// request has landed: the distance that counts is the shortest one in the stream.
+#ifndef VLA_Q4_WD
+#define VLA_Q4_WD 4    // weight ring depth of the small-batch and grouped launches (4 or 8)
+#endif
+#ifndef VLA_Q4_XA
+#define VLA_Q4_XA 4    // x sets (steps of x in flight) of 32- and 64-row tiles (4 or 8)
+#endif
+#ifndef VLA_Q4_XAG
+#define VLA_Q4_XAG 2   // x sets of grouped 128-row tiles (2 or 4)
+#endif
+
 namespace vla {
 namespace {
 
@@ -405,16 +421,20 @@ __device__ __forceinline__ void q4_gemm_m32_body(
   // they are needed -- harmless where a step is ~1000 cycles long.  Small row tiles have short
   // steps, so they keep four x sets: x(t+1) was requested three steps ago, ahead of every
   // weight load that step t does not need anyway, and the weights get their full three steps.
-  constexpr int XAHEAD = MT <= 2 ? 4 : 2;
+  constexpr int XAHEAD = MT <= 2 ? VLA_Q4_XA : (GROUPED ? VLA_Q4_XAG : 2);
+  // Weight ring: the words of a step are requested WD - 1 steps ahead.
+  constexpr int WD = (MT <= 2 || GROUPED) ? VLA_Q4_WD : 4;
+  static_assert(WD == 4 || WD == 8, "ring depth");
   // G2: zcur holds the constants of step t's group; on even steps znew receives those of the
-  // next group (the name the previous group has just released).
+  // group WD - 2 steps ahead (the name the previous group has just released).
   auto k_step = [&](int t, const WStep& wcur, WStep& wnew, XSet& xnew, const XSet& xpark,
                     const ZS& zcur, ZS& znew) {
     const int buf = t & 1;
     load_x(t + XAHEAD, xnew);
-    load_w(t + 3, wnew);
+    load_w(t + WD - 1, wnew);
     if constexpr (G2) {
-      if ((t & 1) == 0) load_zs((k_begin + phys(min(t + 2, nsteps - 2)) * TK) / group_size, znew);
+      if ((t & 1) == 0)
+        load_zs((k_begin + phys(min(t + WD - 2, nsteps - 2)) * TK) / group_size, znew);
     }
     __builtin_amdgcn_sched_barrier(0);               // keep the loads at the top of the step
 
@@ -492,47 +512,52 @@ __device__ __forceinline__ void q4_gemm_m32_body(
 #endif
   };
 
-  WStep w0, w1, w2, w3;
-  XSet xa, xb_;
-  ZS za, zb;                       // G2: groups group0 + 2i in za, group0 + 2i + 1 in zb
-  load_x(0, xa);
-  load_x(1, xb_);
+  // Register rings, rotated by NAME: the loop is unrolled by the weight ring's depth and every
+  // index below is a constant after unrolling.  x(j) lives in set j % XAHEAD, the weights of step
+  // j in set j % WD.
+  WStep wr[WD];
+  XSet xr[XAHEAD];
+  constexpr int ZD = WD / 2;       // G2: the constants of group group0 + i live in zr[i % ZD]
+  ZS zr[ZD];
+#pragma unroll
+  for (int j = 0; j < XAHEAD; ++j) load_x(j, xr[j]);
+  if constexpr (G2) {
+#pragma unroll
+    for (int j = 0; j < ZD - 1; ++j)
+      load_zs((k_begin + phys(min(2 * j, nsteps - 1)) * TK) / group_size, zr[j]);
+  }
+#pragma unroll
+  for (int j = 0; j < WD - 1; ++j) load_w(j, wr[j]);
+  store_x(0, xr[0]);
+  __syncthreads();
+  auto step_u = [&](auto uc, int t) {
+    constexpr int u = decltype(uc)::value;
+    constexpr int zi = (u >> 1) % ZD;
+    k_step(t, wr[u % WD], wr[(u + WD - 1) % WD], xr[u % XAHEAD], xr[(u + 1) % XAHEAD], zr[zi],
+           zr[(zi + ZD - 1) % ZD]);
+  };
+  using std::integral_constant;
   int t = 0;
-  if constexpr (XAHEAD == 4) {
-    XSet xc, xd;                   // x(j) lives in set j % 4
-    load_x(2, xc);
-    load_x(3, xd);
-    if constexpr (G2) load_zs((k_begin + phys(0) * TK) / group_size, za);
-    load_w(0, w0);
-    load_w(1, w1);
-    load_w(2, w2);
-    store_x(0, xa);
-    __syncthreads();
-    for (; t + 4 <= nsteps; t += 4) {
-      k_step(t, w0, w3, xa, xb_, za, zb);
-      k_step(t + 1, w1, w0, xb_, xc, za, zb);
-      k_step(t + 2, w2, w1, xc, xd, zb, za);
-      k_step(t + 3, w3, w2, xd, xa, zb, za);
+  for (; t + WD <= nsteps; t += WD) {
+    step_u(integral_constant<int, 0>{}, t);
+    step_u(integral_constant<int, 1>{}, t + 1);
+    step_u(integral_constant<int, 2>{}, t + 2);
+    step_u(integral_constant<int, 3>{}, t + 3);
+    if constexpr (WD == 8) {
+      step_u(integral_constant<int, 4>{}, t + 4);
+      step_u(integral_constant<int, 5>{}, t + 5);
+      step_u(integral_constant<int, 6>{}, t + 6);
+      step_u(integral_constant<int, 7>{}, t + 7);
     }
-    if (t < nsteps) k_step(t, w0, w3, xa, xb_, za, zb);
-    if (t + 1 < nsteps) k_step(t + 1, w1, w0, xb_, xc, za, zb);
-    if (t + 2 < nsteps) k_step(t + 2, w2, w1, xc, xd, zb, za);
-  } else {
-    if constexpr (G2) load_zs((k_begin + phys(0) * TK) / group_size, za);
-    load_w(0, w0);
-    load_w(1, w1);
-    load_w(2, w2);
-    store_x(0, xa);
-    __syncthreads();
-    for (; t + 4 <= nsteps; t += 4) {
-      k_step(t, w0, w3, xa, xb_, za, zb);
-      k_step(t + 1, w1, w0, xb_, xa, za, zb);
-      k_step(t + 2, w2, w1, xa, xb_, zb, za);
-      k_step(t + 3, w3, w2, xb_, xa, zb, za);
-    }
-    if (t < nsteps) k_step(t, w0, w3, xa, xb_, za, zb);
-    if (t + 1 < nsteps) k_step(t + 1, w1, w0, xb_, xa, za, zb);
-    if (t + 2 < nsteps) k_step(t + 2, w2, w1, xa, xb_, zb, za);
+  }
+  if (t < nsteps) step_u(integral_constant<int, 0>{}, t);
+  if (t + 1 < nsteps) step_u(integral_constant<int, 1>{}, t + 1);
+  if (t + 2 < nsteps) step_u(integral_constant<int, 2>{}, t + 2);
+  if constexpr (WD == 8) {
+    if (t + 3 < nsteps) step_u(integral_constant<int, 3>{}, t + 3);
+    if (t + 4 < nsteps) step_u(integral_constant<int, 4>{}, t + 4);
+    if (t + 5 < nsteps) step_u(integral_constant<int, 5>{}, t + 5);
+    if (t + 6 < nsteps) step_u(integral_constant<int, 6>{}, t + 6);
   }
 
 #ifdef VLA_Q4_STAMP

@@ -72,6 +72,9 @@ class QuantMixtralMoE(nn.Module):
 
     def route(self, hidden_states: torch.Tensor):
         router_logits = torch.matmul(hidden_states, self.gate)
+        if self.num_total_experts <= 64 and router_logits.is_cuda:
+            # softmax, top-k and renormalisation in one launch (same values as the lines below)
+            return ops.moe_route_topk(router_logits, self.top_k)
         routing_weights = torch.softmax(router_logits, dim=1, dtype=torch.float)
         routing_weights, selected_experts = torch.topk(routing_weights, self.top_k, dim=-1)
         routing_weights /= routing_weights.sum(dim=-1, keepdim=True)
