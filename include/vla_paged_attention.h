@@ -270,7 +270,7 @@ int vla_silu_and_mul(void* out, const void* input, int num_tokens, int d, int dt
  * (vllm/attention/backends/rocm_flash_attn.py:305-383).  query/out [T, num_heads, head_size],
  * key/value [T, num_kv_heads, head_size], row strides in elements; cu_seqlens [num_seqs + 1]
  * int32 on the device (the reference's seq_start_loc); alibi_slopes [num_heads] f32 or NULL
- * (bias slope * (j - i)).  fp16 / bf16, head_size 64/80/96/112/128; other shapes:
+ * (bias slope * (j - i)).  fp16 / bf16, head_size 24/64/80/96/112/128; other shapes:
  * VLA_ERR_HEAD_SIZE / VLA_ERR_DTYPE (the caller keeps its previous path for those). */
 int vla_prefill_attention(void* out, const void* query, const void* key, const void* value,
                           const int* cu_seqlens, int num_seqs, int max_seqlen, int num_heads,
@@ -287,7 +287,8 @@ int vla_prefill_attention(void* out, const void* query, const void* key, const v
  * alibi_slopes as above with absolute positions; sliding_window > 0 keeps keys less than that
  * many positions behind the query (0 / negative: off).  kv_cache_dtype/kv_scale as for
  * paged_attention: a byte cache is decoded with the codec that wrote it.  fp16 / bf16,
- * head_size 64/80/96/112/128, block_size 16/32/64 (and 8 for a 16-bit cache). */
+ * head_size 64/80/96/112/128 (and 24 with a 16-bit cache, the smallest size of
+ * tests/kernels/test_prefix_prefill.py), block_size 16/32/64 (and 8 for a 16-bit cache). */
 int vla_prefix_prefill_attention(void* out, const void* query, const void* key, const void* value,
                                  const void* key_cache, const void* value_cache,
                                  const int* block_tables, int max_blocks_per_seq,

@@ -54,7 +54,7 @@ def test_prefill_matches_oracle(ops, dt, d, heads, alibi):
 
 
 @pytest.mark.parametrize("dt", [O.DT_F16, O.DT_BF16])
-@pytest.mark.parametrize("d", [80, 96, 112])
+@pytest.mark.parametrize("d", [24, 80, 96, 112])
 def test_prefill_other_head_sizes(ops, dt, d):
     _run(ops, [1, 17, 64, 129, 300, 5], 4, 2, d, dt, False, seed=d)
 

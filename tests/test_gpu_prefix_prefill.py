@@ -104,6 +104,33 @@ def test_prefix_shapes(ops, dt, d, bs, kv_fp8):
     _run(ops, d + bs, [1, 40, 129, 200], [100, 0, 63, 257], 4, 2, d, bs, dt, kv_fp8=kv_fp8)
 
 
+@pytest.mark.parametrize("dt", [O.DT_F16, O.DT_BF16])
+@pytest.mark.parametrize("qpk", [1, 8])
+@pytest.mark.parametrize("bs", [8, 32])
+@pytest.mark.parametrize("window", [0, 64])
+def test_prefix_head_size_24(ops, dt, qpk, bs, window):
+    """The smallest head of the reference's grid (tests/kernels/test_prefix_prefill.py HEAD_SIZES
+    = [128, 96, 24]): three 8-dim chunks per row, so the last 16-deep slice of the q.K product is
+    half padding.  Unused cache slots hold NaN patterns in _run, so any padding that is read
+    without being zeroed shows."""
+    ql, cl = _random_lens(24 + qpk + bs, 5, 1, 200)
+    _run(ops, 24 + bs + window, ql, cl, 8, 8 // qpk, 24, bs, dt, window=window)
+
+
+def test_prefix_head_size_24_needs_a_16_bit_cache(ops):
+    """A byte cache packs 16 dims per K piece ([D/16][BS][16]): no such layout exists for 24 dims,
+    and the entry point says so (the reference's 'Unsupported head size') before it reads one."""
+    from vllm_legacy_amd import _lib
+    assert not ops.prefix_prefill_supported(torch.float16, 24, 16, "fp8")
+    assert ops.prefix_prefill_supported(torch.float16, 24, 16, "auto")
+    buf = torch.zeros(4096, dtype=torch.int32, device="cuda")
+    p = buf.data_ptr()
+    st = _lib.lib().vla_prefix_prefill_attention(
+        p, p, p, p, p, p, p, 4, p, p, p, 1, 5, 4, 4, 24, 16, 96, 96, 96, 96, 1536, 384, 0.2, None, 0,
+        _lib.F16, _lib.kv_dtype_code("fp8"), 1.0, None)
+    assert st == 1          # VLA_ERR_HEAD_SIZE
+
+
 @pytest.mark.parametrize("bs", [8, 64])
 def test_prefix_other_block_sizes(ops, bs):
     _run(ops, bs, [33, 5, 130], [70, 129, 8], 4, 1, 128, bs, O.DT_F16)

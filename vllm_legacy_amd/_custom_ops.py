@@ -277,7 +277,7 @@ def prefill_attention(out: torch.Tensor, query: torch.Tensor, key: torch.Tensor,
 
 
 def prefill_attention_supported(dtype: torch.dtype, head_size: int) -> bool:
-    return dtype in (torch.float16, torch.bfloat16) and head_size in (64, 80, 96, 112, 128)
+    return dtype in (torch.float16, torch.bfloat16) and head_size in (24, 64, 80, 96, 112, 128)
 
 
 def prefix_prefill_attention(out: torch.Tensor, query: torch.Tensor, key: torch.Tensor,
@@ -323,6 +323,8 @@ def prefix_prefill_attention(out: torch.Tensor, query: torch.Tensor, key: torch.
 def prefix_prefill_supported(dtype: torch.dtype, head_size: int, block_size: int,
                              kv_cache_dtype: str = "auto") -> bool:
     sizes = (16, 32, 64) if kv_cache_dtype != "auto" else (8, 16, 32, 64)
+    if kv_cache_dtype != "auto" and head_size % 16:
+        return False        # a byte cache packs 16 dims per K piece
     return prefill_attention_supported(dtype, head_size) and block_size in sizes
 
 

@@ -157,11 +157,13 @@ __global__ __launch_bounds__(PF_THREADS, D == 112 ? 1 : 2) void prefill_attentio
   constexpr int DP = D <= 64 ? 64 : 128;
   constexpr int RB = DP * 2;                // bytes per K/V row in LDS
   constexpr int CH = D / 8;                 // live 16-byte chunks per row
-  constexpr int KS = D / 16;                // 16-deep MFMA slices of the S^T product
+  constexpr int KS = (D + 15) / 16;         // 16-deep MFMA slices of the S^T product (the last one
+                                            // half zeros when D is an odd number of 8-dim chunks)
   constexpr int ND = (D + 31) / 32;         // 32-dim output tiles (the last one may be half used)
   constexpr int LD = (PF_BN * CH + PF_THREADS - 1) / PF_THREADS;  // 16-byte loads per thread, tile
   constexpr bool LD_EXACT = (PF_BN * CH) % PF_THREADS == 0;
-  static_assert(D % 16 == 0 && D <= 128 && D >= 16, "head size");
+  static_assert(D % 8 == 0 && D <= 128 && D >= 16, "head size");
+  static_assert(!(FP8 && D % 16), "a byte cache packs 16 dims per 16-byte K piece");
   static_assert(PF_BN * RB >= D * PF_BN * 2, "transposed V image fits");
   __shared__ __attribute__((aligned(16))) unsigned char k_lds[PF_BN * RB];
   __shared__ __attribute__((aligned(16))) unsigned char v_lds[PF_BN * RB];
@@ -196,7 +198,15 @@ __global__ __launch_bounds__(PF_THREADS, D == 112 ? 1 : 2) void prefill_attentio
   {
     const T* qp = qb + (int64_t)min(qrow, n_new - 1) * p.q_stride;
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) qf[ks] = *reinterpret_cast<const u32x4*>(qp + 16 * ks + 8 * h);
+    for (int ks = 0; ks < KS; ++ks)
+      qf[ks] = (D % 16 == 0 || 2 * ks + h < CH) ? *reinterpret_cast<const u32x4*>(qp + 16 * ks + 8 * h)
+                                                : u32x4{0, 0, 0, 0};
+  }
+  if constexpr (D % 16 != 0) {
+    // the chunk past the head in the last slice of every K row: never written by a tile, read
+    // against zero query dims -- it must hold zeros, not whatever the LDS held (0 * NaN)
+    if (tid < PF_BN)
+      *reinterpret_cast<u32x4*>(k_lds + tid * RB + 16 * k_swz<DP>(tid, CH)) = u32x4{0, 0, 0, 0};
   }
   constexpr float kLog2e = 1.4426950408889634f;
   const float scale2 = p.scale * kLog2e;
@@ -484,7 +494,9 @@ using namespace vla;
 
 namespace {
 
-bool pf_head_size_ok(int d) { return d == 64 || d == 80 || d == 96 || d == 112 || d == 128; }
+bool pf_head_size_ok(int d) {
+  return d == 24 || d == 64 || d == 80 || d == 96 || d == 112 || d == 128;
+}
 
 template <bool PREFIX, bool FP8, bool WIN>
 void pf_launch(const PrefillParams& p, int head_size, int dtype, dim3 grid, hipStream_t s) {
@@ -493,6 +505,9 @@ void pf_launch(const PrefillParams& p, int head_size, int dtype, dim3 grid, hipS
                      dim3(PF_THREADS), 0, s, p)
 #define VLA_PF_D(ST)                     \
   switch (head_size) {                   \
+    case 24:                             \
+      if constexpr (!FP8) VLA_PF(ST, 24); \
+      break;                             \
     case 64: VLA_PF(ST, 64); break;      \
     case 80: VLA_PF(ST, 80); break;      \
     case 96: VLA_PF(ST, 96); break;      \
@@ -553,6 +568,7 @@ extern "C" int vla_prefix_prefill_attention(
   if (kv_dtype != VLA_KV_AUTO && kv_dtype != VLA_KV_FP8_E4M3) return VLA_ERR_KV_DTYPE;
   if (!pf_head_size_ok(head_size)) return VLA_ERR_HEAD_SIZE;
   const bool fp8 = kv_dtype == VLA_KV_FP8_E4M3;
+  if (fp8 && head_size % 16) return VLA_ERR_HEAD_SIZE;   // no [D/16][BS][16] K layout exists
   // a 64-key tile is a whole number of blocks, and a 16-byte piece of a value row stays in a block
   if (!(block_size == 16 || block_size == 32 || block_size == 64 || (!fp8 && block_size == 8)))
     return VLA_ERR_BLOCK_SIZE;
