@@ -71,6 +71,52 @@ def test_paged_attention_large_heads_small_blocks_fp32(ops, version, head_size, 
 
 
 @pytest.mark.parametrize("version", ["v1", "v2"])
+@pytest.mark.parametrize("num_heads", [(32, 8), (12, 12), (8, 1)])
+@pytest.mark.parametrize("head_size", [64, 80, 128])
+@pytest.mark.parametrize("use_alibi", [False, True])
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("kv_fp8", [False, True])
+def test_block_size_8(ops, version, num_heads, head_size, use_alibi, dt, kv_fp8):
+    """8-token blocks (the smallest the reference builds, attention_kernels.cu:789-803) on the
+    throughput kernel: a 16-token tile spans two blocks, a byte cache's value rows are 8 bytes."""
+    seed = zlib.crc32(repr((version, num_heads, head_size, use_alibi, dt, kv_fp8)).encode()) % 1000
+    c = T.make_attention_case(seed, 6, num_heads, head_size, 8, dt, kv_fp8, use_alibi,
+                              max_seq_len=1300, num_blocks=400)
+    out = T.run_hip_attention(ops, c, version)
+    _check(out, T.oracle_attention(c, version), dt, kv_fp8)
+
+
+@pytest.mark.parametrize("kv_fp8", [False, True])
+@pytest.mark.parametrize("version", ["v1", "v2"])
+def test_block_size_8_edges_and_poisoned_tails(ops, kv_fp8, version):
+    """Lengths around block, tile, step and partition boundaries with 8-token blocks; every cache
+    slot past a sequence's end, and every unused block, holds NaN."""
+    seq_lens = [1, 7, 8, 9, 15, 16, 17, 63, 64, 65, 511, 512, 513, 1030]
+    c = T.make_attention_case(21, len(seq_lens), (32, 8), 128, 8, O.DT_F16, kv_fp8, False,
+                              max_seq_len=max(seq_lens), num_blocks=1900, seq_lens=seq_lens,
+                              unique_blocks=True)
+    want = T.oracle_attention(c, version)
+    kc, vc = c.t_kc.clone(), c.t_vc.clone()
+    poison = 0x7F if kv_fp8 else float("nan")
+    used = set()
+    for s, n in enumerate(c.seq_lens):
+        nb = (int(n) + 7) // 8
+        used.update(int(c.block_tables[s, b]) for b in range(nb))
+        off = int(n) % 8
+        if off:
+            last = int(c.block_tables[s, nb - 1])
+            kc[last, :, :, off:, :] = poison
+            vc[last, :, :, off:] = poison
+    for b in range(kc.shape[0]):
+        if b not in used:
+            kc[b] = poison
+            vc[b] = poison
+    c.t_kc, c.t_vc = kc, vc
+    out = T.run_hip_attention(ops, c, version)
+    _check(out, want, O.DT_F16, kv_fp8)
+
+
+@pytest.mark.parametrize("version", ["v1", "v2"])
 @pytest.mark.parametrize("dt", [O.DT_F16, O.DT_F32])
 def test_generic_kernel_on_fast_shapes(ops, version, dt):
     # force the coverage kernel onto a shape the MFMA kernel would take

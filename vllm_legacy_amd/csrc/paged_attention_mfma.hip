@@ -57,6 +57,14 @@ __device__ __forceinline__ u32x4 kv_load(const unsigned char* p) {
 }
 
 
+template <bool NT>
+__device__ __forceinline__ u32x2 kv_load8(const unsigned char* p) {
+  if constexpr (NT)
+    return __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(p));
+  else
+    return *reinterpret_cast<const u32x2*>(p);
+}
+
 constexpr int kThreads = 256;
 constexpr int kWaves = 4;
 
@@ -106,7 +114,10 @@ __device__ __forceinline__ u32x4 mask_tokens(u32x4 v, int nvalid) {
 }
 
 // D: head size (a multiple of 16; the q.K contraction is padded with zero query dims up to the
-// next multiple of 4 K chunks), BS: KV block size (16 or 32).
+// next multiple of 4 K chunks), BS: KV block size (8, 16 or 32).  With 8-token blocks a 16-token
+// tile spans two blocks: a lane's K load picks its block by its token (lanes 0-7 / 8-15 of a
+// 16-lane group), a V row of a byte cache is 8 bytes, so a lane's 16 tokens of one head dim are
+// two 8-byte loads from two blocks; a 16-bit V row is exactly one 16-byte load.
 // KVNT: nontemporal K / V loads (a template parameter: behind a run-time branch the compiler
 // merges the two otherwise identical load groups and drops the hint)
 template <class S, bool FP8, int D, int BS, bool PARTITIONED, bool KVNT>
@@ -123,7 +134,8 @@ __global__ __launch_bounds__(kThreads, 2) void pa_mfma_kernel(AttnParams p, int 
   constexpr int PM = FP8 ? 2 : 1;          // MFMAs fed by one V load
   constexpr int CE = FP8 ? 1 : 2;          // cache element bytes
   constexpr int P_PITCH = STEP * 2 + 16;   // bytes per head row of the probability tile
-  static_assert(D % 16 == 0 && (BS == 16 || BS == 32), "head size multiple of 16, block 16 or 32");
+  static_assert(D % 16 == 0 && (BS == 8 || BS == 16 || BS == 32), "head size multiple of 16, block 8/16/32");
+  constexpr int NB = BS == 8 ? STEP / 8 : NT;   // block-table entries a step looks up
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -178,8 +190,8 @@ __global__ __launch_bounds__(kThreads, 2) void pa_mfma_kernel(AttnParams p, int 
   const int64_t blk_bytes = p.kv_block_stride * CE;
   // per-lane byte offsets inside a block; a 16-token tile t starts at token (16 t) % BS of its
   // block, and a lane's V load covers tile g (fp8: 16 tokens) or half of tile g >> 1 (8 tokens)
-  const int k_lane_off = (g * kBS + c) * 16;  // chunk g (+4j), token c (+ tile offset)
-  const int v_tok_off = FP8 ? (16 * g) % kBS : (16 * (g >> 1)) % kBS + 8 * (g & 1);
+  const int k_lane_off = (g * kBS + (BS == 8 ? (c & 7) : c)) * 16;  // chunk g (+4j), token c (+ tile offset)
+  const int v_tok_off = BS == 8 ? 0 : FP8 ? (16 * g) % kBS : (16 * (g >> 1)) % kBS + 8 * (g & 1);
   const int v_lane_off = (c * kBS + v_tok_off) * CE;
   // K chunk g + 4j lies past the head for the last j of some lanes: those lanes re-read chunk g
   // (finite data) against zero query dims
@@ -195,22 +207,26 @@ __global__ __launch_bounds__(kThreads, 2) void pa_mfma_kernel(AttnParams p, int 
   const int nsteps = (tok_end - tok_begin + STEP - 1) / STEP;
 
   // block numbers of a step, clamped to the last block that holds live tokens
-  auto step_blocks = [&](int step, int (&blk)[NT]) {
+  auto step_blocks = [&](int step, int (&blk)[NB]) {
     const int b0 = (tok_begin + step * STEP) / kBS;
 #pragma unroll
-    for (int t = 0; t < NT; ++t) blk[t] = bt[min(b0 + (16 * t) / kBS, last_blk)];
+    for (int t = 0; t < NB; ++t)
+      blk[t] = bt[min(b0 + (BS == 8 ? t : (16 * t) / kBS), last_blk)];
   };
-  auto load_k = [&](const int (&blk)[NT], u32x4 (&kb)[NT * KL]) {
+  auto load_k = [&](const int (&blk)[NB], u32x4 (&kb)[NT * KL]) {
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-      const unsigned char* kp = kbase + (int64_t)blk[t] * blk_bytes + k_lane_off +
+      int kblk;
+      if constexpr (BS == 8) kblk = (c & 8) ? blk[2 * t + 1] : blk[2 * t];
+      else kblk = blk[t];
+      const unsigned char* kp = kbase + (int64_t)kblk * blk_bytes + k_lane_off +
                                 ((16 * t) % kBS) * 16;
 #pragma unroll
       for (int j = 0; j < KL; ++j) kb[t * KL + j] = kv_load<KVNT>(kp + k_j_off[j]);
     }
   };
 
-  int cur_blk[NT];
+  int cur_blk[NB];
   u32x4 kb[NT * KL];
   if (wave < nsteps) {
     step_blocks(wave, cur_blk);
@@ -222,15 +238,34 @@ __global__ __launch_bounds__(kThreads, 2) void pa_mfma_kernel(AttnParams p, int 
     const bool tail = step_base + STEP > tok_end;  // wave-uniform
 
     // block numbers of this wave's next step (used after q.K)
-    int nxt_blk[NT] = {};
+    int nxt_blk[NB] = {};
     const bool has_next = step + kWaves < nsteps;
     if (has_next) step_blocks(step + kWaves, nxt_blk);
 
     // ---- V loads of this step (consumed after the softmax)
     u32x4 vb[ND];
-    {
+    if constexpr (BS == 8 && FP8) {
+      // tokens 16 g .. + 7 in block 2 g of the step, + 8 .. + 15 in block 2 g + 1
+      int vlo = cur_blk[0], vhi = cur_blk[1];
+#pragma unroll
+      for (int t = 1; t < NT; ++t) {
+        vlo = (g == t) ? cur_blk[2 * t] : vlo;
+        vhi = (g == t) ? cur_blk[2 * t + 1] : vhi;
+      }
+      const unsigned char* vp0 = vbase + (int64_t)vlo * blk_bytes + v_lane_off;
+      const unsigned char* vp1 = vbase + (int64_t)vhi * blk_bytes + v_lane_off;
+#pragma unroll
+      for (int n = 0; n < ND; ++n) {
+        const u32x2 a = kv_load8<KVNT>(vp0 + n * (16 * kBS)), b = kv_load8<KVNT>(vp1 + n * (16 * kBS));
+        vb[n] = u32x4{a[0], a[1], b[0], b[1]};
+      }
+    } else {
       int vblk;
-      if constexpr (FP8) {
+      if constexpr (BS == 8) {           // 16-bit cache: tokens 8 g .. + 7 of the step are block g
+        vblk = cur_blk[0];
+#pragma unroll
+        for (int t = 1; t < NB; ++t) vblk = (g == t) ? cur_blk[t] : vblk;
+      } else if constexpr (FP8) {
         vblk = cur_blk[0];
 #pragma unroll
         for (int t = 1; t < NT; ++t) vblk = (g == t) ? cur_blk[t] : vblk;
@@ -332,7 +367,7 @@ __global__ __launch_bounds__(kThreads, 2) void pa_mfma_kernel(AttnParams p, int 
     }
 
 #pragma unroll
-    for (int t = 0; t < NT; ++t) cur_blk[t] = nxt_blk[t];
+    for (int t = 0; t < NB; ++t) cur_blk[t] = nxt_blk[t];
   }
 
   // ---- merge the waves
@@ -412,7 +447,8 @@ int launch_b(const AttnParams& p, hipStream_t s) {
 
 template <class S, bool FP8, int D>
 int launch_t(const AttnParams& p, hipStream_t s) {
-  return p.block_size == 16 ? launch_b<S, FP8, D, 16>(p, s) : launch_b<S, FP8, D, 32>(p, s);
+  return p.block_size == 16 ? launch_b<S, FP8, D, 16>(p, s)
+         : p.block_size == 32 ? launch_b<S, FP8, D, 32>(p, s) : launch_b<S, FP8, D, 8>(p, s);
 }
 
 template <class S, bool FP8>
@@ -432,7 +468,7 @@ int launch_d(const AttnParams& p, hipStream_t s) {
 }  // namespace
 
 int launch_paged_attention_mfma(const AttnParams& p, int dtype, int kv_dtype, hipStream_t s) {
-  if (p.block_size != 16 && p.block_size != 32) return -1;
+  if (p.block_size != 8 && p.block_size != 16 && p.block_size != 32) return -1;
   if (dtype != VLA_F16 && dtype != VLA_BF16) return -1;
   const bool fp8 = kv_dtype == VLA_KV_FP8_E4M3;
   const int ce = fp8 ? 1 : 2;
