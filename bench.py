@@ -49,7 +49,7 @@ def parse():
     ap.add_argument("--kv", default="fp8", choices=["fp8", "auto"])
     ap.add_argument("--dtype", default="f16", choices=["f16", "bf16"],
                     help="model dtype (the int4 linears need f16; bf16 goes with --quant none)")
-    ap.add_argument("--model", default="llama3-8b", choices=["llama3-8b", "llama3-70b", "tiny"])
+    ap.add_argument("--model", default="llama3-8b", choices=["llama3-8b", "llama3-70b", "mixtral-8x7b", "tiny"])
     ap.add_argument("--no-graph", action="store_true", help="run the step eagerly")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--rank-of", type=int, default=1,
@@ -364,7 +364,7 @@ def main():
     from vllm_legacy_amd.model.llama_decode import LlamaConfig, LlamaDecodeModel
 
     cfg = {"llama3-8b": LlamaConfig.llama3_8b, "llama3-70b": LlamaConfig.llama3_70b,
-           "tiny": LlamaConfig.tiny}[args.model]()
+           "mixtral-8x7b": LlamaConfig.mixtral_8x7b, "tiny": LlamaConfig.tiny}[args.model]()
     cfg.num_hidden_layers = args.layers
     if args.rank_of > 1:
         assert world == 1
@@ -553,7 +553,44 @@ def main():
     # ---- second kernel family: the int4 dequant-GEMMs of one layer at M = batch, timed the same
     # way (HIP events on their stream, every layer's own weights so nothing is cache-resident)
     gemm = None
-    if args.quant != "none":
+    moe = None
+    if args.quant != "none" and cfg.num_local_experts > 0:
+        # the sparse-MoE block of one layer (router, pair sort, two grouped int4 launches around
+        # SiLU * mul, weighted sum), every layer its own experts, replayed from one graph; what
+        # bounds it at decode sizes is the stream of ALL local experts' weights
+        with torch.cuda.stream(stream), torch.inference_mode():
+            xm = torch.empty((B, cfg.hidden_size), dtype=model.dtype, device=device).normal_(0, 1)
+            for lyr in model.layers:
+                lyr.block_sparse_moe(xm)
+            torch.cuda.synchronize()
+            moe_graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(moe_graph, stream=stream):
+                for lyr in model.layers:
+                    lyr.block_sparse_moe(xm)
+            moe_graph.replay()
+            torch.cuda.synchronize()
+            ts = []
+            for _ in range(5):
+                a, b_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record(stream)
+                moe_graph.replay()
+                b_.record(stream)
+                torch.cuda.synchronize()
+                ts.append(a.elapsed_time(b_) / len(model.layers))
+            moe_ms = sorted(ts)[len(ts) // 2]
+        blk = layer0.block_sparse_moe
+        n_loc = len(blk.expert_indicies)
+        w_bytes = n_loc * 3 * cfg.hidden_size * cfg.intermediate_size // 2
+        w_bytes += n_loc * 3 * (cfg.hidden_size * cfg.intermediate_size // 128) * 5 // 2   # zeros, scales
+        moe = {
+            "kernel": "quantized sparse-MoE block: q4_gemm_m32_kernel grouped launches (w13, w2) + routing glue",
+            "bound": "hbm", "achieved": round(w_bytes / (moe_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": round(w_bytes / (moe_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            "traffic": None, "algorithmic_bytes_per_block": w_bytes, "block_ms": round(moe_ms, 4),
+            "local_experts": n_loc, "rows_per_expert_mean": B * cfg.num_experts_per_tok / cfg.num_local_experts,
+            "timing": f"graph replay of {len(model.layers)} blocks, every block its own experts, HIP events / blocks",
+        }
+    if args.quant != "none" and cfg.num_local_experts == 0:
         names = ("qkv_proj", "o_proj", "gate_up_proj", "down_proj")
         with torch.cuda.stream(stream), torch.inference_mode():
             xs = {}
@@ -645,7 +682,9 @@ def main():
 
     if rank == 0:
         result = {
-            "metric": "decode tokens/s, Llama-3-8B AWQ-int4 fp8-KV, bs=256 seq=4k (+ achieved HBM GB/s of paged attention in `roofline`)",
+            "metric": ("decode tokens/s, Llama-3-8B AWQ-int4 fp8-KV, bs=256 seq=4k (+ achieved HBM GB/s of paged attention in `roofline`)"
+                       if args.model == "llama3-8b" else
+                       f"decode tokens/s, {args.model} {args.quant} {args.kv}-KV, bs={B} seq={S} (+ achieved HBM GB/s of paged attention in `roofline`)"),
             "value": round(B / (ms_per_step * 1e-3), 2),
             "unit": "tokens/s",
             "n_gpus": args.gpus,
@@ -698,6 +737,8 @@ def main():
         }
         if gemm is not None:
             result["roofline_gemm"] = gemm
+        if moe is not None:
+            result["roofline_moe"] = moe
         if world == 1 and not args.no_cpu_baseline:
             try:
                 result["cpu_baseline"] = cpu_baseline(args)

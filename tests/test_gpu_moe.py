@@ -220,3 +220,78 @@ def test_moe_tensor_parallel_matches_single_rank(world, xgmi, tmp_path):
     # partial sums are rounded to fp16 per rank before the all-reduce: a few fp16 ulps
     np.testing.assert_allclose(z["grouped"], want, atol=8e-3, rtol=8e-3)
     np.testing.assert_allclose(z["dense"], want, atol=8e-3, rtol=8e-3)
+
+
+def test_mixtral_decode_stack_matches_the_dense_expert_loop():
+    """A two-layer Mixtral-shaped decode step (attention + quantized sparse-MoE block per layer,
+    vllm/model_executor/models/mixtral_quant.py:283-296): the logits of the routed, grouped
+    execution equal those of the reference's loop of every expert over every token, eagerly and
+    replayed from a captured graph (the block has no host synchronisation)."""
+    from vllm_legacy_amd import _custom_ops as ops
+    from vllm_legacy_amd.attention.backends.gfx950_paged import Gfx950PagedAttentionMetadata
+    from vllm_legacy_amd.model.llama_decode import LlamaConfig, LlamaDecodeModel
+    dev = torch.device("cuda", 0)
+    cfg = LlamaConfig(hidden_size=512, intermediate_size=1024, num_hidden_layers=2,
+                      num_attention_heads=8, num_key_value_heads=2, head_dim=64, vocab_size=1024,
+                      max_position_embeddings=512, num_local_experts=8, num_experts_per_tok=2)
+    model = LlamaDecodeModel(cfg, quant="awq", kv_cache_dtype="fp8", device=dev, seed=5)
+    for layer in model.layers:
+        lins = [layer.qkv_proj, layer.o_proj]
+        for e in layer.block_sparse_moe.experts:
+            lins += [e.w13, e.w2]
+        for lin in lins:
+            lin.scales.data = (lin.scales.data.float() * 0.2).half()
+    bs = 16
+    seq_lens = np.array([1, 5, 16, 17, 100, 200, 37, 64] * 5, dtype=np.int32)
+    B = len(seq_lens)
+    max_blocks = (int(seq_lens.max()) + bs - 1) // bs
+    num_blocks = B * max_blocks + 3
+    rng = np.random.default_rng(3)
+    block_tables = rng.permutation(num_blocks)[:B * max_blocks].reshape(B, max_blocks).astype(np.int32)
+    positions = (seq_lens - 1).astype(np.int64)
+    slots = np.array([block_tables[b, p // bs] * bs + p % bs for b, p in enumerate(positions)], dtype=np.int64)
+    ids = torch.from_numpy(rng.integers(0, cfg.vocab_size, B).astype(np.int64)).to(dev)
+    g = torch.Generator(device=dev).manual_seed(9)
+    kv0 = []
+    for _ in range(cfg.num_hidden_layers):
+        src = torch.empty(model.kv_cache_shape(num_blocks, bs), dtype=torch.float16, device=dev)
+        src.uniform_(-1, 1, generator=g)
+        c = torch.empty(src.shape, dtype=torch.uint8, device=dev)
+        ops.convert_fp8(c, src)
+        kv0.append(c)
+    meta = Gfx950PagedAttentionMetadata(
+        num_prefills=0, num_prefill_tokens=0, num_decode_tokens=B,
+        slot_mapping=torch.from_numpy(slots).to(dev), seq_lens=None,
+        seq_lens_tensor=torch.from_numpy(seq_lens).to(dev), max_query_len=None,
+        max_prefill_seq_len=0, max_decode_seq_len=int(seq_lens.max()), query_start_loc=None,
+        seq_start_loc=None, use_cuda_graph=True, context_lens_tensor=None,
+        block_tables=torch.from_numpy(block_tables).to(dev))
+    pos = torch.from_numpy(positions).to(dev)
+
+    def run():
+        caches = [c.clone() for c in kv0]
+        with torch.inference_mode():
+            return model.compute_logits(model(ids, pos, caches, meta)).float()
+
+    grouped = run()
+    for layer in model.layers:
+        layer.block_sparse_moe.forward = layer.block_sparse_moe.forward_dense
+    dense = run()
+    for layer in model.layers:
+        del layer.block_sparse_moe.forward
+    assert torch.isfinite(grouped).all()
+    span = dense.abs().max().item()
+    assert (grouped - dense).abs().max().item() <= 4e-3 * max(1.0, span)
+    assert torch.equal(grouped.argmax(-1), dense.argmax(-1))
+    # the same step from a graph
+    caches = [c.clone() for c in kv0]
+    stream = torch.cuda.Stream()
+    with torch.cuda.stream(stream), torch.inference_mode():
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=stream):
+            out = model.compute_logits(model(ids, pos, caches, meta))
+        for c, c0 in zip(caches, kv0):
+            c.copy_(c0)
+        graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out.float(), grouped)

@@ -43,6 +43,15 @@ class LlamaConfig:
     rms_norm_eps: float = 1e-5
     rope_theta: float = 500000.0
     max_position_embeddings: int = 8192
+    # > 0: the MLP of every layer is a quantized sparse-MoE block of this many experts
+    # (vllm/model_executor/models/mixtral_quant.py:93-156, :283-296)
+    num_local_experts: int = 0
+    num_experts_per_tok: int = 2
+
+    @staticmethod
+    def mixtral_8x7b() -> "LlamaConfig":
+        return LlamaConfig(vocab_size=32000, rope_theta=1e6, max_position_embeddings=32768,
+                           num_local_experts=8, num_experts_per_tok=2)
 
     @staticmethod
     def llama3_8b() -> "LlamaConfig":
@@ -109,7 +118,7 @@ class QuantLinear(nn.Module):
 class LlamaDecodeLayer(nn.Module):
 
     def __init__(self, cfg: LlamaConfig, quant: str, kv_cache_dtype: str, tp: int, device,
-                 generator, dtype):
+                 generator, dtype, layer_index: int = 0):
         super().__init__()
         self.cfg, self.tp = cfg, tp
         self.hq = cfg.num_attention_heads // tp
@@ -122,10 +131,20 @@ class LlamaDecodeLayer(nn.Module):
         self.qkv_proj = QuantLinear(cfg.hidden_size, self.q_size + 2 * self.kv_size, quant, 128,
                                     device, generator, dtype)
         self.o_proj = QuantLinear(self.q_size, cfg.hidden_size, quant, 128, device, generator, dtype)
-        self.gate_up_proj = QuantLinear(cfg.hidden_size, 2 * cfg.intermediate_size // tp, quant, 128,
-                                        device, generator, dtype)
-        self.down_proj = QuantLinear(cfg.intermediate_size // tp, cfg.hidden_size, quant, 128,
-                                     device, generator, dtype)
+        self.block_sparse_moe = None
+        if cfg.num_local_experts > 0:
+            # experts are split over the ranks, not sharded (mixtral_quant.py:109-123); every rank
+            # draws all experts from the same seed and keeps its own
+            from vllm_legacy_amd.model.mixtral_moe import QuantMixtralMoE
+            self.block_sparse_moe = QuantMixtralMoE(cfg.hidden_size, cfg.intermediate_size,
+                                                    cfg.num_local_experts, cfg.num_experts_per_tok,
+                                                    quant, 128, device, seed=7919 + layer_index,
+                                                    dtype=dtype)
+        else:
+            self.gate_up_proj = QuantLinear(cfg.hidden_size, 2 * cfg.intermediate_size // tp, quant,
+                                            128, device, generator, dtype)
+            self.down_proj = QuantLinear(cfg.intermediate_size // tp, cfg.hidden_size, quant, 128,
+                                         device, generator, dtype)
         self.attn = Attention(self.hq, d, d**-0.5, self.hkv, kv_cache_dtype=kv_cache_dtype,
                               dtype=dtype)
 
@@ -167,6 +186,9 @@ class LlamaDecodeLayer(nn.Module):
         hidden = self.o_proj(attn_out, defer_reduce=fuse)
         hidden = PendingAllReduce(hidden) if fuse_norm else tensor_model_parallel_all_reduce(hidden, dt)
         hidden, residual = self.post_attention_layernorm(hidden, residual)
+        if self.block_sparse_moe is not None:
+            # router, routed experts and the block's own all-reduce (mixtral_quant.py:129-156)
+            return self.block_sparse_moe(hidden), residual
         # gate_up is column-parallel: whatever K slices it made are summed by the activation
         hidden = self.down_proj(self.act_fn(self.gate_up_proj(hidden, defer_reduce=True), dt),
                                 defer_reduce=fuse)
@@ -189,8 +211,8 @@ class LlamaDecodeModel(nn.Module):
         emb.normal_(0, 1.0, generator=g)
         self.embed_tokens = nn.Parameter(emb, requires_grad=False)
         self.layers = nn.ModuleList([
-            LlamaDecodeLayer(cfg, quant, kv_cache_dtype, tp, device, g, dtype)
-            for _ in range(cfg.num_hidden_layers)
+            LlamaDecodeLayer(cfg, quant, kv_cache_dtype, tp, device, g, dtype, layer_index=i)
+            for i in range(cfg.num_hidden_layers)
         ])
         self.norm = RMSNorm(cfg.hidden_size, cfg.rms_norm_eps, dtype, device)
         # [vocab shard, hidden] as the reference's ParallelLMHead keeps it
