@@ -88,7 +88,8 @@ def record(src, dst, note, workload):
 def gemm_traffic(fetch_csv, write_csv, dst, note):
     """HBM bytes of one layer's four int4 GEMM launches at M = 256 from two PMC summaries (this
     tool's `pmc` output for FETCH_SIZE and for WRITE_SIZE of `tools/gemm_bench.py --m 256`): the
-    unsplit kernel is gate_up, the split-K kernel averages qkv, o and down (equal launch counts)."""
+    unsplit kernel is gate_up; each split-K kernel serves as many of qkv, o and down as its dispatch
+    count says (every shape is launched equally often)."""
     import json
 
     def per_kernel(path, counter):
@@ -106,12 +107,15 @@ def gemm_traffic(fetch_csv, write_csv, dst, note):
            "workload": {"m": 256, "model": "llama3-8b", "quant": "int4", "rank_of": 1, "world": 1},
            "kernels": {}}
     total = 0.0
+    # every layer shape is launched equally often: a kernel's launches per layer are its
+    # dispatches over those of the unsplit kernel (gate_up, one launch per layer)
+    unsplit = [n for name, (_, n) in f.items()
+               if re.search(r"q4_gemm_\w+?_kernelILi\dELb(\d)E", name).group(1) == "0"]
+    per_layer = min(unsplit) if unsplit else max(n for _, n in f.values())
     for name in f:
         fb, n = f[name]
         wb = w.get(name, (0.0, 0))[0]
-        # template arguments <ZOFF, SPLIT, ...>: ILi<z>ELb<split>E...
-        split = re.search(r"q4_gemm_\w+?_kernelILi\dELb(\d)E", name).group(1) == "1"
-        launches = 3 if split else 1
+        launches = max(1, round(n / per_layer))
         rec["kernels"][name] = {"fetch_bytes": round(fb), "write_bytes": round(wb), "dispatches": n,
                                 "launches_per_layer": launches}
         total += launches * (fb + wb)
