@@ -162,7 +162,8 @@ class QuantMixtralMoE(nn.Module):
         selected_experts = selected_experts.contiguous()
         act_order = w13[3] is not None
         pairs = num_tokens * self.top_k
-        if ((pairs + 63) // 64) * (n_local + 1) > ops.MOE_SORT_MAX_COUNTERS:
+        if (n_local + 1 > 128 or self.top_k > 8 or
+                ((pairs + 63) // 64) * (n_local + 1) > ops.MOE_SORT_MAX_COUNTERS):
             return self._forward_grouped_torch(hidden_states, routing_weights, selected_experts)
         offsets, sorted_token, pair_row, row_bucket = ops.moe_sort_pairs(
             selected_experts, self._bucket_of, n_local + 1, want_row_bucket=act_order)
