@@ -1481,7 +1481,7 @@ static int q4_gemm_run(const void* x, const int32_t* qweight, const int32_t* qze
   // fits; unset: 128 x 64 wave tiles for unsliced layers whose K parts are at least 16 steps
   // (gate_up 4096 x 28672 at batch 256: 74 -> 69 us), 128 x 32 tiles over 3 stages otherwise
   // (qkv / o / down: 30.3 / 25.2 / 45.5 -> 29.3 / 24.6 / 44.3 us).
-  static const int dma_env = getenv("VLA_Q4_DMA") ? atoi(getenv("VLA_Q4_DMA")) : -1;
+  static const int dma_env = (getenv("VLA_Q4_DMA") && *getenv("VLA_Q4_DMA")) ? atoi(getenv("VLA_Q4_DMA")) : -1;
   const bool dma_ok = (int64_t)m * k < (1ll << 30) && (int64_t)n * 32 < (1ll << 30);   // 32-bit lane offsets
   Q4Shape shape = pick_shape(m, n, k, group);
   int splits = shape.splits;
