@@ -1646,10 +1646,11 @@ static int q4_gemm_grouped_run(const void* x, const int* x_rows, const int32_t* 
   // tall tile costs a short row block registers, not MFMAs, while a short tile costs a row block
   // that overflows it a second pass over the set's weights -- and routing spreads rows unevenly
   // (top-2 of 8 over 256 tokens: 64 rows per expert on average, half of the experts above that).
-  // Mixtral-8x7B block from a graph, 64- against 128-row tiles: 64 tokens 0.258 / 0.266 ms, 256
-  // tokens 0.409 / 0.377, 1024 tokens 1.04 / 0.98 (96 tokens 0.280 / 0.269): 128-row tiles from 24 rows per set on average.
+  // Mixtral-8x7B block from a graph, 64- against 128-row tile templates on one box: 16 tokens
+  // 0.236 / 0.212-0.223 ms, 64 tokens 0.237 / 0.223-0.225, 96 tokens 0.242-0.256 / 0.227-0.231,
+  // 256 tokens 0.409 / 0.377, 1024 tokens 1.04 / 0.98: 128-row tiles at every size.
   // VLA_Q4_GROUPED_MT=2/4 overrides (kernel studies).
-  int mt = total_rows / num_sets >= 24 ? 4 : 2;
+  int mt = 4;
   if (const char* e = getenv("VLA_Q4_GROUPED_MT")) {
     const int v = atoi(e);
     if (v == 2 || v == 4) mt = v;
