@@ -1,0 +1,113 @@
+"""GPU parity tests for the int4 dequant-GEMM at decode batches of at most 16 rows
+(q4_gemm_skinny.hip: 16x16x32 MFMAs with the weights as the A operand, x straight from global
+memory, K parts of a workgroup summed through LDS, K slices across workgroups as fp32 slabs).
+
+As for the larger batches the reference holds no fixture for the GEMM itself: outputs are compared
+with the oracle's fp32-accumulate product of the bit-exact dequantised weights, and with the
+library's own 32-row kernel (VLA_Q4_SKINNY=0 is read when the library first decides, so the
+comparison runs on the launch-shape override instead).
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as O
+from tests import pa_testlib as T
+from tests.test_gpu_quant import _awq_weights, _cuda, _gptq_weights
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from vllm_legacy_amd import _custom_ops
+    return _custom_ops
+
+
+def _close(got, want_bits, long_sum):
+    want = O.from_bits(want_bits, O.DT_F16)
+    rtol, atol = (3e-3, 8e-3) if long_sum else (2e-3, 2e-3)
+    np.testing.assert_allclose(got.float().cpu().numpy(), want, rtol=rtol, atol=atol)
+
+
+# group 128 takes chunks of four K steps, groups of 32 / 64 / 96 chunks of one; 328 and 8 columns
+# leave a last strip that is mostly outside the matrix; 14336 / 128 = 112 chunks do not divide
+# evenly among 8 or 16 waves
+@pytest.mark.parametrize("m", [1, 2, 5, 16])
+@pytest.mark.parametrize("k,n,group", [(512, 256, 128), (1024, 328, 64), (384, 8, 96), (128, 64, 32),
+                                       (4096, 4096, 128), (14336, 4096, 128), (4096, 6144, 128),
+                                       (2048, 1024, 2048)])
+def test_awq_packed_gemm_small_batches(ops, m, k, n, group):
+    if k * n > 4096 * 4096 and m not in (1, 16):
+        pytest.skip("largest shapes at two batch sizes")
+    rng = np.random.default_rng(m + k + n)
+    qw, qz, sc = _awq_weights(rng, k, n, group)
+    x = O.to_bits(rng.uniform(-1, 1, (m, k)).astype(np.float32), O.DT_F16)
+    pw, pz = ops.awq_repack(_cuda(qw), _cuda(qz))
+    got = ops.q4_gemm_packed(_cuda(x, O.DT_F16), pw, pz, _cuda(sc, O.DT_F16), 0)
+    torch.cuda.synchronize()
+    assert got.shape == (m, n)
+    _close(got, O.gemm_f16(x, O.awq_dequantize(qw, sc, qz)), k > 4096)
+
+
+@pytest.mark.parametrize("m", [1, 9, 16])
+@pytest.mark.parametrize("k,n,group", [(1024, 8192, 128), (8192, 1280, 128), (512, 320, 64)])
+def test_gptq_exllama_gemm_small_batches(ops, m, k, n, group):
+    """GPTQ stores zero - 1 (q_gemm.cu:1413): the other zero offset of the same kernel."""
+    rng = np.random.default_rng(m + k)
+    qw, qz, sc = _gptq_weights(rng, k, n, group)
+    x = O.to_bits(rng.uniform(-1, 1, (m, k)).astype(np.float32), O.DT_F16)
+    gq = _cuda(qw.copy())
+    none = torch.empty(0, dtype=torch.int32, device="cuda")
+    ops.gptq_shuffle(gq, none, 4)
+    got = ops.gptq_gemm(_cuda(x, O.DT_F16), gq, _cuda(qz), _cuda(sc, O.DT_F16), none, True, 4)
+    torch.cuda.synchronize()
+    _close(got, O.gemm_f16(x, O.gptq_dequantize(qw, qz, sc)), k > 4096)
+
+
+@pytest.mark.parametrize("tune", ["4,1", "8,1", "16,1", "4,4", "8,2", "16,8", "8,7"])
+def test_every_launch_shape_gives_the_same_product(ops, tune):
+    """Waves per workgroup and K slices change the order of the fp32 sums only."""
+    rng = np.random.default_rng(3)
+    m, k, n, group = 7, 3584, 1096, 128
+    qw, qz, sc = _awq_weights(rng, k, n, group)
+    x = O.to_bits(rng.uniform(-1, 1, (m, k)).astype(np.float32), O.DT_F16)
+    pw, pz = ops.awq_repack(_cuda(qw), _cuda(qz))
+    old = os.environ.get("VLA_Q4_SKINNY_TUNE")
+    os.environ["VLA_Q4_SKINNY_TUNE"] = tune
+    try:
+        got = ops.q4_gemm_packed(_cuda(x, O.DT_F16), pw, pz, _cuda(sc, O.DT_F16), 0)
+        torch.cuda.synchronize()
+    finally:
+        if old is None:
+            del os.environ["VLA_Q4_SKINNY_TUNE"]
+        else:
+            os.environ["VLA_Q4_SKINNY_TUNE"] = old
+    _close(got, O.gemm_f16(x, O.awq_dequantize(qw, sc, qz)), False)
+
+
+def test_small_batch_product_from_a_graph_and_with_padding_rows_untouched(ops):
+    """Rows past the batch are never written (the kernel computes them from a repeated row and
+    drops them), and the launch replays from a graph."""
+    rng = np.random.default_rng(8)
+    m, k, n, group = 3, 4096, 6144, 128
+    qw, qz, sc = _awq_weights(rng, k, n, group)
+    x = O.to_bits(rng.uniform(-1, 1, (m, k)).astype(np.float32), O.DT_F16)
+    pw, pz = ops.awq_repack(_cuda(qw), _cuda(qz))
+    xd, scd = _cuda(x, O.DT_F16), _cuda(sc, O.DT_F16)
+    eager = ops.q4_gemm_packed(xd, pw, pz, scd, 0)
+    torch.cuda.synchronize()
+    stream = torch.cuda.Stream()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(stream):
+        ops.q4_gemm_packed(xd, pw, pz, scd, 0)
+        torch.cuda.synchronize()
+        with torch.cuda.graph(graph, stream=stream):
+            out = ops.q4_gemm_packed(xd, pw, pz, scd, 0)
+        out.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+    assert torch.equal(out, eager)
+    _close(out, O.gemm_f16(x, O.awq_dequantize(qw, sc, qz)), False)

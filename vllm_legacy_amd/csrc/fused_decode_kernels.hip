@@ -272,14 +272,16 @@ __global__ __launch_bounds__(1024) void add_rms_norm_slabs_kernel(
 // silu_and_mul whose input [tokens][2 d] arrives as split-K slabs: each half is summed over the
 // slabs (fp32, slab order) and rounded to the model dtype as the GEMM's own reduction would,
 // then out = silu(gate) * up with the activation kernel's arithmetic
-// (csrc/activation_kernels.cu:14-33).  Four outputs per thread.
+// (csrc/activation_kernels.cu:14-33).  Four outputs per thread; grid (tokens, column parts): a
+// decode batch of a few tokens would otherwise leave one workgroup per token to walk the whole
+// row (14 336 outputs of Llama-3-8B at batch 1: 10 us).
 template <class S>
 __global__ __launch_bounds__(256) void silu_and_mul_slabs_kernel(
     const float* __restrict__ slabs, int num_slabs, int64_t slab_stride,
     typename S::T* __restrict__ out, int d) {
   const int64_t row = blockIdx.x;
   const float* src = slabs + row * 2 * d;
-  for (int i = threadIdx.x * 4; i < d; i += blockDim.x * 4) {
+  for (int i = (blockIdx.y * blockDim.x + threadIdx.x) * 4; i < d; i += gridDim.y * blockDim.x * 4) {
     f32x4 g = *reinterpret_cast<const f32x4*>(src + i);
     f32x4 u = *reinterpret_cast<const f32x4*>(src + d + i);
     for (int p = 1; p < num_slabs; ++p) {
@@ -397,7 +399,13 @@ extern "C" int vla_silu_and_mul_splitk(const float* slabs, int num_slabs, int64_
   if (!slabs || !out || num_slabs < 1 || num_tokens < 0 || d <= 0 || d % 4 ||
       ((uintptr_t)slabs % 16) || (slab_stride % 4))
     return VLA_ERR_ARG;
-  VLA_BY_DTYPE(dtype, hipLaunchKernelGGL((silu_and_mul_slabs_kernel<S>), dim3(num_tokens), dim3(256),
+  // column parts until the launch has about two workgroups per CU (one pass of 1024 outputs each
+  // at most)
+  int gy = (512 + num_tokens - 1) / num_tokens;
+  const int passes = (d / 4 + 255) / 256;
+  if (gy > passes) gy = passes;
+  if (gy < 1) gy = 1;
+  VLA_BY_DTYPE(dtype, hipLaunchKernelGGL((silu_and_mul_slabs_kernel<S>), dim3(num_tokens, gy), dim3(256),
                                          0, (hipStream_t)stream, slabs, num_slabs, slab_stride,
                                          (typename S::T*)out, d));
   VLA_HIP_CHECK(hipGetLastError());

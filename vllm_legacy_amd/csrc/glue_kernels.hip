@@ -233,8 +233,11 @@ extern "C" int vla_silu_and_mul(void* out, const void* input, int num_tokens, in
   if (!out || !input || num_tokens < 0 || d <= 0) return VLA_ERR_ARG;
   if (!vec_ok(out, d, dtype) || !vec_ok(input, d, dtype)) return VLA_ERR_ARG;
   const int n = dtype == VLA_F32 ? 4 : 8;
+  // column parts: one pass per workgroup while the launch stays under about two workgroups per
+  // CU, at most eight parts otherwise
   int gy = (d / n + 255) / 256;
-  if (gy > 8) gy = 8;
+  const int cap = num_tokens >= 64 ? 8 : (512 + num_tokens - 1) / num_tokens;
+  if (gy > cap) gy = cap;
   VLA_BY_DTYPE(dtype, hipLaunchKernelGGL((silu_and_mul_kernel<S>), dim3(num_tokens, gy), dim3(256),
                                          0, (hipStream_t)stream, (typename S::T*)out,
                                          (const typename S::T*)input, d));

@@ -1303,6 +1303,14 @@ __global__ __launch_bounds__(256) void awq_repack_zeros_kernel(const uint32_t* _
 
 using namespace vla;
 
+namespace vla {
+// q4_gemm_skinny.hip: batches of at most 16 rows
+bool q4_skinny_shape(int m, int n, int k, int group, int* nwv, int* splits, int* cs);
+int launch_q4_gemm_skinny(const void* x, const void* qw, const void* qz, const void* scales,
+                          void* dst, int m, int n, int k, int group, int zero_offset, int nwv,
+                          int splits, int cs, hipStream_t s);
+}  // namespace vla
+
 // The 32x32 kernel's launch shape: nw = waves (32 columns each) per workgroup, splits = K slices.
 // From sweeps on MI355X at M = 256 over the Llama-3-8B layer shapes at TP 1/2/4/8:
 //  * 256-column workgroups for wide, deep layers; 128-column ones (two fit a CU) when the layer is
@@ -1455,7 +1463,10 @@ static hipError_t launch_dma2(dim3 grid, hipStream_t s, const _Float16* x, const
 
 extern "C" int64_t vla_q4_gemm_workspace_bytes(int m, int n, int k, int group) {
   if (m <= 0 || n <= 0 || k <= 0 || group <= 0) return 0;
-  const int s = pick_shape(m, n, k, group).splits;
+  int sk_nwv = 0, sk_splits = 0, sk_cs = 0;
+  const int s = q4_skinny_shape(m, n, k, group, &sk_nwv, &sk_splits, &sk_cs)
+                    ? sk_splits
+                    : pick_shape(m, n, k, group).splits;
   return s > 1 ? (int64_t)s * m * n * 4 : 0;
 }
 
@@ -1483,6 +1494,25 @@ static int q4_gemm_run(const void* x, const int32_t* qweight, const int32_t* qze
   // (qkv / o / down: 30.3 / 25.2 / 45.5 -> 29.3 / 24.6 / 44.3 us).
   static const int dma_env = (getenv("VLA_Q4_DMA") && *getenv("VLA_Q4_DMA")) ? atoi(getenv("VLA_Q4_DMA")) : -1;
   const bool dma_ok = (int64_t)m * k < (1ll << 30) && (int64_t)n * 32 < (1ll << 30);   // 32-bit lane offsets
+  int sk_nwv = 0, sk_splits = 0, sk_cs = 0;
+  if (q4_skinny_shape(m, n, k, group, &sk_nwv, &sk_splits, &sk_cs)) {
+    // at most 16 rows: one pass over the weights, see q4_gemm_skinny.hip
+    if (sk_splits > 1 && (!workspace || workspace_bytes < (int64_t)sk_splits * m * n * 4 ||
+                          ((uintptr_t)workspace % 16) || ((int64_t)m * n) % 4))
+      sk_splits = 1;
+    launch_q4_gemm_skinny(x, qweight, qzeros, scales, sk_splits > 1 ? workspace : out, m, n, k,
+                          group, zero_offset, sk_nwv, sk_splits, sk_cs, s);
+    VLA_HIP_CHECK(hipGetLastError());
+    if (sk_splits > 1 && reduce) {
+      const int64_t elems = (int64_t)m * n;
+      hipLaunchKernelGGL(q4_splitk_reduce_kernel, dim3((unsigned)((elems / 4 + 255) / 256)),
+                         dim3(256), 0, s, (const float*)workspace, (_Float16*)out, elems, sk_splits);
+      VLA_HIP_CHECK(hipGetLastError());
+    } else if (sk_splits > 1 && num_slabs) {
+      *num_slabs = sk_splits;
+    }
+    return VLA_OK;
+  }
   Q4Shape shape = pick_shape(m, n, k, group);
   int splits = shape.splits;
   int dma_stages = dma_env;            // decided below, once the slicing is final
