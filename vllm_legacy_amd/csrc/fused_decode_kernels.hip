@@ -230,7 +230,10 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
 
 // x = model_dtype(sum of slabs); residual = x + residual; out = rms_norm(residual) * weight.
 // Four elements per lane and pass (16-byte slab loads).
-template <class S>
+// KEEP: passes of the row a thread holds in registers between the two loops (0: re-read the row
+// from `residual`); with it a row of up to KEEP * 4096 elements is read once and the second loop
+// does not wait for the first one's stores to come back through L2.
+template <class S, int KEEP>
 __global__ __launch_bounds__(1024) void add_rms_norm_slabs_kernel(
     const float* __restrict__ slabs, int num_slabs, int64_t slab_stride,
     typename S::T* __restrict__ out, typename S::T* __restrict__ residual,
@@ -238,7 +241,9 @@ __global__ __launch_bounds__(1024) void add_rms_norm_slabs_kernel(
   __shared__ float red[16];
   const int64_t base = (int64_t)blockIdx.x * hidden;
   float var = 0.f;
-  for (int i = threadIdx.x * 4; i < hidden; i += blockDim.x * 4) {
+  float xk[KEEP > 0 ? KEEP : 1][4];
+  int pass = 0;
+  for (int i = threadIdx.x * 4; i < hidden; i += blockDim.x * 4, ++pass) {
     // all slab loads of this chunk are issued before the first one is consumed
     f32x4 part[8];
 #pragma unroll
@@ -256,14 +261,28 @@ __global__ __launch_bounds__(1024) void add_rms_norm_slabs_kernel(
       const float x = rnd<S>(rnd<S>(s[e]) + S::to_f32(residual[base + i + e]));
       residual[base + i + e] = S::from_f32(x);
       var += x * x;
+      if constexpr (KEEP > 0) {
+#pragma unroll
+        for (int q = 0; q < KEEP; ++q)
+          if (q == pass) xk[q][e] = x;
+      }
     }
   }
   var = block_sum(var, red);
   const float inv = rsqrtf(var / (float)hidden + eps);
-  for (int i = threadIdx.x * 4; i < hidden; i += blockDim.x * 4) {
+  pass = 0;
+  for (int i = threadIdx.x * 4; i < hidden; i += blockDim.x * 4, ++pass) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const float x = S::to_f32(residual[base + i + e]);
+      float x;
+      if constexpr (KEEP > 0) {
+        x = xk[0][e];
+#pragma unroll
+        for (int q = 1; q < KEEP; ++q)
+          if (q == pass) x = xk[q][e];
+      } else {
+        x = S::to_f32(residual[base + i + e]);
+      }
       out[base + i + e] = S::from_f32(rnd<S>(x * inv) * S::to_f32(weight[i + e]));
     }
   }
@@ -384,10 +403,16 @@ extern "C" int vla_fused_add_rms_norm_splitk(const float* slabs, int num_slabs, 
     return VLA_ERR_ARG;
   const int chunks = hidden_size / 4;
   const int threads = chunks >= 1024 ? 1024 : ((chunks + 63) / 64) * 64;
-  VLA_BY_DTYPE(dtype, hipLaunchKernelGGL((add_rms_norm_slabs_kernel<S>), dim3(num_tokens),
-                                         dim3(threads), 0, (hipStream_t)stream, slabs, num_slabs, slab_stride,
-                                         (typename S::T*)out, (typename S::T*)residual,
-                                         (const typename S::T*)weight, epsilon, hidden_size));
+#define VLA_ARS(KEEP_)                                                                          \
+  hipLaunchKernelGGL((add_rms_norm_slabs_kernel<S, KEEP_>), dim3(num_tokens), dim3(threads), 0,  \
+                     (hipStream_t)stream, slabs, num_slabs, slab_stride, (typename S::T*)out,    \
+                     (typename S::T*)residual, (const typename S::T*)weight, epsilon, hidden_size)
+  if (chunks <= 2 * threads) {
+    VLA_BY_DTYPE(dtype, VLA_ARS(2));
+  } else {
+    VLA_BY_DTYPE(dtype, VLA_ARS(0));
+  }
+#undef VLA_ARS
   VLA_HIP_CHECK(hipGetLastError());
   return VLA_OK;
 }

@@ -63,7 +63,11 @@ struct Vec16 {  // 16 bytes of model-dtype elements
 };
 
 // FUSED: input += residual first (result also written to residual), output goes to `input`.
-template <class S, bool FUSED>
+// KEEP: passes of the row a thread holds in registers between the two loops (0: re-read the row).
+// A row of up to KEEP * 256 * N elements is then read once -- the second loop of the generic form
+// loads what the first has just stored, a round trip through L2 that a decode batch of a few
+// tokens (one workgroup each, nothing else in flight) waits out in full.
+template <class S, bool FUSED, int KEEP>
 __global__ __launch_bounds__(256) void rms_norm_kernel(typename S::T* __restrict__ out,
                                                        typename S::T* __restrict__ input,
                                                        typename S::T* __restrict__ residual,
@@ -74,6 +78,39 @@ __global__ __launch_bounds__(256) void rms_norm_kernel(typename S::T* __restrict
   __shared__ float red[4];
   const int64_t base = (int64_t)blockIdx.x * hidden;
   float var = 0.f;
+  if constexpr (KEEP > 0) {
+    float xk[KEEP][N], wk[KEEP][N];
+#pragma unroll
+    for (int p = 0; p < KEEP; ++p) {
+      const int i = (p * blockDim.x + threadIdx.x) * N;
+      if (i < hidden) {
+        V::load(input + base + i, xk[p]);
+        V::load(weight + i, wk[p]);
+        if constexpr (FUSED) {
+          float r[N];
+          V::load(residual + base + i, r);
+#pragma unroll
+          for (int e = 0; e < N; ++e) xk[p][e] = rnd<S>(xk[p][e] + r[e]);
+          V::store(residual + base + i, xk[p]);
+        }
+#pragma unroll
+        for (int e = 0; e < N; ++e) var += xk[p][e] * xk[p][e];
+      }
+    }
+    var = block_sum_f32(var, red);
+    const float inv = rsqrtf(var / (float)hidden + eps);
+    typename S::T* dst = FUSED ? input : out;
+#pragma unroll
+    for (int p = 0; p < KEEP; ++p) {
+      const int i = (p * blockDim.x + threadIdx.x) * N;
+      if (i < hidden) {
+#pragma unroll
+        for (int e = 0; e < N; ++e) xk[p][e] = rnd<S>(rnd<S>(xk[p][e] * inv) * wk[p][e]);
+        V::store(dst + base + i, xk[p]);
+      }
+    }
+    return;
+  }
   for (int i = threadIdx.x * N; i < hidden; i += blockDim.x * N) {
     float x[N];
     V::load(input + base + i, x);
@@ -173,10 +210,17 @@ extern "C" int vla_rms_norm(void* out, const void* input, const void* weight, fl
   if (!vec_ok(out, hidden_size, dtype) || !vec_ok(input, hidden_size, dtype) ||
       !vec_ok(weight, hidden_size, dtype))
     return VLA_ERR_ARG;
-  VLA_BY_DTYPE(dtype, hipLaunchKernelGGL((rms_norm_kernel<S, false>), dim3(num_tokens), dim3(256),
-                                         0, (hipStream_t)stream, (typename S::T*)out,
-                                         (typename S::T*)input, (typename S::T*)nullptr,
-                                         (const typename S::T*)weight, epsilon, hidden_size));
+  const bool keep = hidden_size <= 2 * 256 * (dtype == VLA_F32 ? 4 : 8);
+#define VLA_RMS(KEEP_)                                                                          \
+  hipLaunchKernelGGL((rms_norm_kernel<S, false, KEEP_>), dim3(num_tokens), dim3(256), 0,         \
+                     (hipStream_t)stream, (typename S::T*)out, (typename S::T*)input,            \
+                     (typename S::T*)nullptr, (const typename S::T*)weight, epsilon, hidden_size)
+  if (keep) {
+    VLA_BY_DTYPE(dtype, VLA_RMS(2));
+  } else {
+    VLA_BY_DTYPE(dtype, VLA_RMS(0));
+  }
+#undef VLA_RMS
   VLA_HIP_CHECK(hipGetLastError());
   return VLA_OK;
 }
@@ -190,10 +234,17 @@ extern "C" int vla_fused_add_rms_norm(void* input, void* residual, const void* w
   if (!vec_ok(input, hidden_size, dtype) || !vec_ok(residual, hidden_size, dtype) ||
       !vec_ok(weight, hidden_size, dtype))
     return VLA_ERR_ARG;
-  VLA_BY_DTYPE(dtype, hipLaunchKernelGGL((rms_norm_kernel<S, true>), dim3(num_tokens), dim3(256), 0,
-                                         (hipStream_t)stream, (typename S::T*)nullptr,
-                                         (typename S::T*)input, (typename S::T*)residual,
-                                         (const typename S::T*)weight, epsilon, hidden_size));
+  const bool keep = hidden_size <= 2 * 256 * (dtype == VLA_F32 ? 4 : 8);
+#define VLA_RMS(KEEP_)                                                                          \
+  hipLaunchKernelGGL((rms_norm_kernel<S, true, KEEP_>), dim3(num_tokens), dim3(256), 0,          \
+                     (hipStream_t)stream, (typename S::T*)nullptr, (typename S::T*)input,        \
+                     (typename S::T*)residual, (const typename S::T*)weight, epsilon, hidden_size)
+  if (keep) {
+    VLA_BY_DTYPE(dtype, VLA_RMS(2));
+  } else {
+    VLA_BY_DTYPE(dtype, VLA_RMS(0));
+  }
+#undef VLA_RMS
   VLA_HIP_CHECK(hipGetLastError());
   return VLA_OK;
 }

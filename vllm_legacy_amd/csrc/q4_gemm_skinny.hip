@@ -21,6 +21,13 @@
 //  * a workgroup is NWV waves on the SAME 64 columns, each walking its own part of the
 //    workgroup's K range; their sums meet through LDS once, in wave order.  Layers with few
 //    columns are also cut into K slices across workgroups (fp32 slabs, as the larger kernels).
+//
+// Measured and not taken: batches of 17-32 rows on the same kernel with a second MFMA per
+// dequantised word on rows 16-31 (two x fragments per step, chunks of two steps to stay under 170
+// registers): layer (qkv + o + gate_up + down of Llama-3-8B) at batch 32 65.2 us against 59.0 on the
+// LDS-staged 32-row kernel, at batch 24 60.9 against 58.1 -- the second x stream from L2 costs
+// more than the barrier-free loop saves.  Chunks of two steps (108 registers, four waves per SIMD)
+// change nothing at batch 16 either (tools/exp/sweep_skinny_cs.sh).
 #include <cstdio>
 #include <cstdlib>
 
