@@ -111,3 +111,68 @@ def test_small_batch_product_from_a_graph_and_with_padding_rows_untouched(ops):
         torch.cuda.synchronize()
     assert torch.equal(out, eager)
     _close(out, O.gemm_f16(x, O.awq_dequantize(qw, sc, qz)), False)
+
+
+# ---------------------------------------------------------------- grouped (MoE experts at decode)
+# num_sets x ceil(oc / 64) must exceed 256 for the grouped launch to take this kernel (enough
+# column strips to fill the chip without K slices); 8 sets x 2112 columns = 264 strips.
+@pytest.mark.parametrize("counts,tail,gather", [([5, 0, 16, 1, 0, 3, 2, 7], 0, False),
+                                                ([1, 1, 1, 1, 1, 1, 1, 1], 3, False),
+                                                ([0, 0, 0, 9, 0, 0, 0, 0], 0, True),
+                                                ([16, 16, 2, 0, 1, 4, 8, 3], 5, True)])
+@pytest.mark.parametrize("ic,oc,group", [(512, 2112, 128), (1024, 2176, 64)])
+def test_grouped_product_of_sets_of_at_most_16_rows(ops, counts, tail, gather, ic, oc, group):
+    """Several weight sets in one launch where no set holds more than 16 rows: every row block
+    equals the oracle's product with its own set, empty sets are fine, rows behind the last set
+    come back zero (or stay untouched when the rows are gathered through x_rows)."""
+    rng = np.random.default_rng(ic + sum(counts) + tail)
+    sets = len(counts)
+    ws = [_awq_weights(rng, ic, oc, group) for _ in range(sets)]
+    packed = [ops.awq_repack(_cuda(qw), _cuda(qz)) for qw, qz, _ in ws]
+    pw = torch.stack([p[0] for p in packed]).contiguous()
+    pz = torch.stack([p[1] for p in packed]).contiguous()
+    sc = torch.stack([_cuda(w[2], O.DT_F16) for w in ws]).contiguous()
+    rows = sum(counts) + tail
+    offsets = torch.tensor(np.concatenate([[0], np.cumsum(counts)]), dtype=torch.int32, device="cuda")
+    if gather:
+        tokens = 11
+        src = O.to_bits(rng.uniform(-1, 1, (tokens, ic)).astype(np.float32), O.DT_F16)
+        x_rows = rng.integers(0, tokens, rows).astype(np.int32)
+        x = src[x_rows]
+        got = ops.q4_gemm_grouped(_cuda(src, O.DT_F16), pw, pz, sc, offsets, 0, max(counts),
+                                  x_rows=torch.from_numpy(x_rows).cuda())
+    else:
+        x = O.to_bits(rng.uniform(-1, 1, (rows, ic)).astype(np.float32), O.DT_F16)
+        got = ops.q4_gemm_grouped(_cuda(x, O.DT_F16), pw, pz, sc, offsets, 0, max(counts))
+    torch.cuda.synchronize()
+    assert got.shape == (rows, oc)
+    got = got.float().cpu().numpy()
+    start = 0
+    for (qw, qz, s), c in zip(ws, counts):
+        if c:
+            want = O.gemm_f16(x[start:start + c], O.awq_dequantize(qw, s, qz))
+            np.testing.assert_allclose(got[start:start + c], O.from_bits(want, O.DT_F16), rtol=3e-3,
+                                       atol=4e-3)
+        start += c
+    if not gather:
+        assert not got[start:].any()
+
+
+def test_grouped_small_sets_equal_the_tiled_grouped_launch(ops):
+    """The same grouped product with a loose row bound (which keeps it on the LDS-staged tiles)
+    and with the tight one (small-batch kernel): equal within the GEMM tolerance."""
+    rng = np.random.default_rng(77)
+    counts, ic, oc, group = [3, 0, 12, 1, 6, 0, 16, 2], 1024, 2112, 128
+    ws = [_awq_weights(rng, ic, oc, group) for _ in counts]
+    packed = [ops.awq_repack(_cuda(qw), _cuda(qz)) for qw, qz, _ in ws]
+    pw = torch.stack([p[0] for p in packed]).contiguous()
+    pz = torch.stack([p[1] for p in packed]).contiguous()
+    sc = torch.stack([_cuda(w[2], O.DT_F16) for w in ws]).contiguous()
+    rows = sum(counts)
+    x = _cuda(O.to_bits(rng.uniform(-1, 1, (rows, ic)).astype(np.float32), O.DT_F16), O.DT_F16)
+    offsets = torch.tensor(np.concatenate([[0], np.cumsum(counts)]), dtype=torch.int32, device="cuda")
+    tiled = ops.q4_gemm_grouped(x, pw, pz, sc, offsets, 0, rows)
+    small = ops.q4_gemm_grouped(x, pw, pz, sc, offsets, 0, 16)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(small.float().cpu().numpy(), tiled.float().cpu().numpy(), rtol=3e-3,
+                               atol=4e-3)

@@ -51,17 +51,40 @@ struct SkChunk {
   u32x2 s;        // their four scales
 };
 
-template <int ZOFF, bool SPLIT, int NWV, int CS, int NB>
+// GROUPED: several weight sets in one launch (the experts of an MoE block at a decode batch where
+// no expert gets more than 16 rows): blockIdx.y is the set, gp.row_offsets[set] .. [set + 1] its
+// rows of x / out, gp.x_rows (optional) the row of x each product row reads; a set without rows
+// leaves at once.
+struct SkGroups {
+  const int* row_offsets;
+  const int* x_rows;
+  int total_rows;                            // rows of out: the slab pitch of a split product
+  int64_t w_stride, z_stride, s_stride;      // elements between consecutive sets
+};
+
+template <int ZOFF, bool SPLIT, int NWV, int CS, int NB, bool GROUPED = false>
 __global__ __launch_bounds__(64 * NWV) void q4_gemm_skinny_kernel(
     const _Float16* __restrict__ x, const uint32_t* __restrict__ qw,
     const uint32_t* __restrict__ qz, const _Float16* __restrict__ scales, void* __restrict__ outp,
-    int m, int n, int k, int group_size, int k_per_split, int chunks_per_group) {
+    int m, int n, int k, int group_size, int k_per_split, int chunks_per_group,
+    SkGroups gp = SkGroups{}) {
   static_assert(NB == 2 || NB == 3, "ring depth");
   __shared__ f32x4 red[(NWV > 1 ? NWV - 1 : 1) * 4 * 64];
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int c = lane & 15, g = lane >> 4;
+  int row_base = 0, slab_rows = m;
+  if constexpr (GROUPED) {
+    const int set = blockIdx.y;
+    row_base = gp.row_offsets[set];
+    m = min(gp.row_offsets[set + 1] - row_base, 16);
+    if (m <= 0) return;
+    slab_rows = gp.total_rows;
+    qw += (int64_t)set * gp.w_stride;
+    qz += (int64_t)set * gp.z_stride;
+    scales += (int64_t)set * gp.s_stride;
+  }
   const int n0 = blockIdx.x * 64;
   const int col = n0 + 4 * c;
   const int colc = col < n ? col : 0;          // clamped: loads stay in bounds, result unused
@@ -85,7 +108,11 @@ __global__ __launch_bounds__(64 * NWV) void q4_gemm_skinny_kernel(
   const int64_t wstep = (int64_t)n * 16;        // bytes between steps (four k-rows)
 #endif
   const char* xrow = reinterpret_cast<const char*>(x + k_begin);
-  const uint32_t xoff = (uint32_t)(min(c, m - 1) * k + 8 * g) * 2u;
+  int xr = row_base + min(c, m - 1);
+  if constexpr (GROUPED) {
+    if (gp.x_rows) xr = gp.x_rows[xr];
+  }
+  const uint32_t xoff = (uint32_t)(xr * k + 8 * g) * 2u;
   const int grp0 = k_begin / group_size;
   int grp_ctr = (k_begin - grp0 * group_size) / CK;
   const char* zrow = reinterpret_cast<const char*>(qz + (int64_t)grp0 * (n >> 3));
@@ -224,10 +251,11 @@ __global__ __launch_bounds__(64 * NWV) void q4_gemm_skinny_kernel(
     const int oc = n0 + 16 * g + 4 * i;
     if (oc >= n) continue;                       // n % 8 == 0: a quad is inside or outside
     if constexpr (SPLIT) {
-      float* dst = reinterpret_cast<float*>(outp) + ((int64_t)blockIdx.z * m + c) * n + oc;
+      float* dst = reinterpret_cast<float*>(outp) +
+                   ((int64_t)blockIdx.z * slab_rows + row_base + c) * n + oc;
       *reinterpret_cast<f32x4*>(dst) = f32x4{acc[0][i], acc[1][i], acc[2][i], acc[3][i]};
     } else {
-      _Float16* dst = reinterpret_cast<_Float16*>(outp) + (int64_t)c * n + oc;
+      _Float16* dst = reinterpret_cast<_Float16*>(outp) + (int64_t)(row_base + c) * n + oc;
       const f16x2 lo = {(_Float16)acc[0][i], (_Float16)acc[1][i]};
       const f16x2 hi = {(_Float16)acc[2][i], (_Float16)acc[3][i]};
       *reinterpret_cast<u32x2*>(dst) = u32x2{sk_u32(lo), sk_u32(hi)};
@@ -337,6 +365,47 @@ int launch_q4_gemm_skinny(const void* x, const void* qw, const void* qz, const v
 #undef VLA_SK_NB
 #undef VLA_SK_ARGS
   return 0;
+}
+
+// Grouped launch (see SkGroups): unsliced, four waves per workgroup -- the shape of the wide dense
+// layers, which is what `num_sets` times the column strips of an expert projection amount to.
+// The caller has checked that no set holds more than 16 rows.
+int launch_q4_gemm_skinny_grouped(const void* x, const int* x_rows, const void* qw, const void* qz,
+                                  const void* scales, void* out, const int* row_offsets,
+                                  int num_sets, int total_rows, int n, int k, int group,
+                                  int zero_offset, hipStream_t s) {
+  const int cs = group % 128 == 0 ? 4 : 1;
+  const dim3 grid((n + 63) / 64, num_sets, 1);
+  const int cpg = group / (32 * cs);
+  SkGroups gp{};
+  gp.row_offsets = row_offsets;
+  gp.x_rows = x_rows;
+  gp.total_rows = total_rows;
+  gp.w_stride = (int64_t)(k / 8) * n;
+  gp.z_stride = (int64_t)(k / group) * (n / 8);
+  gp.s_stride = (int64_t)(k / group) * n;
+#define VLA_SKG(Z, C)                                                                            \
+  hipLaunchKernelGGL((q4_gemm_skinny_kernel<Z, false, 4, C, 3, true>), grid, dim3(256), 0, s,      \
+                     (const _Float16*)x, (const uint32_t*)qw, (const uint32_t*)qz,               \
+                     (const _Float16*)scales, out, 0, n, k, group, k, cpg, gp)
+  if (zero_offset == 0) {
+    if (cs == 4) VLA_SKG(0, 4); else VLA_SKG(0, 1);
+  } else {
+    if (cs == 4) VLA_SKG(1, 4); else VLA_SKG(1, 1);
+  }
+#undef VLA_SKG
+  return 0;
+}
+
+// Whether a grouped product takes the kernel above: sets of at most 16 rows and enough column
+// strips over all sets to fill the chip without K slices.
+bool q4_skinny_grouped_ok(int max_rows_per_set, int total_rows, int num_sets, int n, int k,
+                          int group) {
+  int nwv = 0, splits = 0, cs = 0;
+  if (max_rows_per_set < 1 || max_rows_per_set > 16) return false;
+  if (!q4_skinny_shape(max_rows_per_set, n, k, group, &nwv, &splits, &cs)) return false;
+  if ((int64_t)total_rows * k >= (1ll << 30)) return false;      // 32-bit lane offsets into x
+  return (int64_t)((n + 63) / 64) * num_sets > 256;
 }
 
 }  // namespace vla

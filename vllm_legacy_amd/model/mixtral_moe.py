@@ -168,18 +168,21 @@ class QuantMixtralMoE(nn.Module):
         offsets, sorted_token, pair_row, row_bucket = ops.moe_sort_pairs(
             selected_experts, self._bucket_of, n_local + 1, want_row_bucket=act_order)
         zo = self._zero_offset
+        # a token chooses an expert at most once: no expert holds more rows than there are tokens
+        # (a decode batch of up to 16 tokens takes the small-batch kernel on this bound)
+        bound = min(pairs, num_tokens)
         if act_order:       # act-ordered experts: each row's columns in its expert's order
             xs = hidden_states.index_select(0, sorted_token)
             xs = torch.gather(xs, 1, w13[3][row_bucket.long()])
-            h = ops.q4_gemm_grouped(xs, w13[0], w13[1], w13[2], offsets, zo, pairs)
+            h = ops.q4_gemm_grouped(xs, w13[0], w13[1], w13[2], offsets, zo, bound)
         else:
-            h = ops.q4_gemm_grouped(hidden_states, w13[0], w13[1], w13[2], offsets, zo, pairs,
+            h = ops.q4_gemm_grouped(hidden_states, w13[0], w13[1], w13[2], offsets, zo, bound,
                                     x_rows=sorted_token)
         h = self.experts[self.expert_indicies[0]].act_fn(h)
         if act_order:
             h = torch.gather(h, 1, w2[3][row_bucket.long()])
         # rows of other ranks' experts (the trailing bucket) are never read by the combine step
-        y = ops.q4_gemm_grouped(h, w2[0], w2[1], w2[2], offsets, zo, pairs, zero_outside=False)
+        y = ops.q4_gemm_grouped(h, w2[0], w2[1], w2[2], offsets, zo, bound, zero_outside=False)
         final = ops.moe_combine(y, routing_weights.contiguous(), selected_experts, pair_row,
                                 self._bucket_of, n_local)
         return tensor_model_parallel_all_reduce(final).view(num_tokens, hidden_dim)
@@ -203,11 +206,12 @@ class QuantMixtralMoE(nn.Module):
         row_expert = local[order]
         if w13[3] is not None:      # act-ordered experts: each row's columns in its expert's order
             xs = torch.gather(xs, 1, w13[3][row_expert])
-        h = ops.q4_gemm_grouped(xs, w13[0], w13[1], w13[2], offsets, zo, rows)
+        bound = min(rows, num_tokens)       # a token chooses an expert at most once
+        h = ops.q4_gemm_grouped(xs, w13[0], w13[1], w13[2], offsets, zo, bound)
         h = self.experts[self.expert_indicies[0]].act_fn(h)
         if w2[3] is not None:
             h = torch.gather(h, 1, w2[3][row_expert])
-        y = ops.q4_gemm_grouped(h, w2[0], w2[1], w2[2], offsets, zo, rows)
+        y = ops.q4_gemm_grouped(h, w2[0], w2[1], w2[2], offsets, zo, bound)
         # fp32 product, then the rounding to the model dtype, as two steps: written as one
         # in-place mixed multiply the compiler may fuse them into a single rounding
         y = (y.float() * routing_weights.reshape(-1)[order].unsqueeze(1)).to(y.dtype)
