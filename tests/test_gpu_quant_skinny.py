@@ -119,10 +119,14 @@ def test_small_batch_product_from_a_graph_and_with_padding_rows_untouched(ops):
 @pytest.mark.parametrize("counts,tail,gather", [([5, 0, 16, 1, 0, 3, 2, 7], 0, False),
                                                 ([1, 1, 1, 1, 1, 1, 1, 1], 3, False),
                                                 ([0, 0, 0, 9, 0, 0, 0, 0], 0, True),
-                                                ([16, 16, 2, 0, 1, 4, 8, 3], 5, True)])
+                                                ([16, 16, 2, 0, 1, 4, 8, 3], 5, True),
+                                                # more than 16 rows in a set: a second and a third
+                                                # 16-row tile of the same launch
+                                                ([20, 0, 33, 1, 5, 0, 48, 2], 0, False),
+                                                ([17, 3, 0, 32, 1, 1, 2, 40], 2, True)])
 @pytest.mark.parametrize("ic,oc,group", [(512, 2112, 128), (1024, 2176, 64)])
-def test_grouped_product_of_sets_of_at_most_16_rows(ops, counts, tail, gather, ic, oc, group):
-    """Several weight sets in one launch where no set holds more than 16 rows: every row block
+def test_grouped_product_of_sets_of_a_few_rows(ops, counts, tail, gather, ic, oc, group):
+    """Several weight sets in one launch where the sets hold a few rows each: every row block
     equals the oracle's product with its own set, empty sets are fine, rows behind the last set
     come back zero (or stay untouched when the rows are gathered through x_rows)."""
     rng = np.random.default_rng(ic + sum(counts) + tail)

@@ -1313,8 +1313,8 @@ bool q4_skinny_grouped_ok(int max_rows_per_set, int total_rows, int num_sets, in
                           int group);
 int launch_q4_gemm_skinny_grouped(const void* x, const int* x_rows, const void* qw, const void* qz,
                                   const void* scales, void* out, const int* row_offsets,
-                                  int num_sets, int total_rows, int n, int k, int group,
-                                  int zero_offset, hipStream_t s);
+                                  int num_sets, int total_rows, int row_tiles, int n, int k,
+                                  int group, int zero_offset, hipStream_t s);
 }  // namespace vla
 
 // The 32x32 kernel's launch shape: nw = waves (32 columns each) per workgroup, splits = K slices.
@@ -1671,10 +1671,11 @@ static int q4_gemm_grouped_run(const void* x, const int* x_rows, const int32_t* 
   if (((uintptr_t)x % 16) || ((uintptr_t)out % 8)) return VLA_ERR_ARG;
   if (total_rows == 0 || max_rows_per_set == 0) return VLA_OK;
   if (q4_skinny_grouped_ok(max_rows_per_set, total_rows, num_sets, n, k, group)) {
-    // no set holds more than 16 rows (a decode batch of a few tokens): the LDS-free small-batch
-    // kernel, one launch over all sets, no K slices
+    // a few rows per set (a decode batch of a few tokens): the LDS-free small-batch kernel, one
+    // launch over all sets and their 16-row tiles, no K slices
     launch_q4_gemm_skinny_grouped(x, x_rows, qweight, qzeros, scales, out, row_offsets, num_sets,
-                                  total_rows, n, k, group, zero_offset, (hipStream_t)stream);
+                                  total_rows, (max_rows_per_set + 15) / 16, n, k, group,
+                                  zero_offset, (hipStream_t)stream);
     VLA_HIP_CHECK(hipGetLastError());
     return VLA_OK;
   }

@@ -52,7 +52,7 @@ struct SkChunk {
 };
 
 // GROUPED: several weight sets in one launch (the experts of an MoE block at a decode batch where
-// no expert gets more than 16 rows): blockIdx.y is the set, gp.row_offsets[set] .. [set + 1] its
+// experts hold a few rows each): blockIdx.y is the set, gp.row_offsets[set] .. [set + 1] its
 // rows of x / out, gp.x_rows (optional) the row of x each product row reads; a set without rows
 // leaves at once.
 struct SkGroups {
@@ -77,7 +77,9 @@ __global__ __launch_bounds__(64 * NWV) void q4_gemm_skinny_kernel(
   int row_base = 0, slab_rows = m;
   if constexpr (GROUPED) {
     const int set = blockIdx.y;
-    row_base = gp.row_offsets[set];
+    // blockIdx.z = 16-row tile of the set: a set with more than 16 rows streams its weights once
+    // per tile (the later ones mostly out of L2 / the Infinity Cache), a tile without rows leaves
+    row_base = gp.row_offsets[set] + 16 * blockIdx.z;
     m = min(gp.row_offsets[set + 1] - row_base, 16);
     if (m <= 0) return;
     slab_rows = gp.total_rows;
@@ -94,7 +96,7 @@ __global__ __launch_bounds__(64 * NWV) void q4_gemm_skinny_kernel(
   const int nch_wg = k_per_split / CK;
   const int ch_begin = (wave * nch_wg) / NWV, ch_end = ((wave + 1) * nch_wg) / NWV;
   const int nch = ch_end - ch_begin;
-  const int k_begin = blockIdx.z * k_per_split + ch_begin * CK;
+  const int k_begin = (GROUPED ? 0 : blockIdx.z * k_per_split) + ch_begin * CK;
 
   // uniform bases walk along K in scalar registers; the lane parts never change
 #if VLA_SK_ABL & 16   // strip-major addressing: a wave's words of a step are 1 KiB contiguous
@@ -369,13 +371,13 @@ int launch_q4_gemm_skinny(const void* x, const void* qw, const void* qz, const v
 
 // Grouped launch (see SkGroups): unsliced, four waves per workgroup -- the shape of the wide dense
 // layers, which is what `num_sets` times the column strips of an expert projection amount to.
-// The caller has checked that no set holds more than 16 rows.
+// row_tiles = ceil(max rows per set / 16).
 int launch_q4_gemm_skinny_grouped(const void* x, const int* x_rows, const void* qw, const void* qz,
                                   const void* scales, void* out, const int* row_offsets,
-                                  int num_sets, int total_rows, int n, int k, int group,
-                                  int zero_offset, hipStream_t s) {
+                                  int num_sets, int total_rows, int row_tiles, int n, int k,
+                                  int group, int zero_offset, hipStream_t s) {
   const int cs = group % 128 == 0 ? 4 : 1;
-  const dim3 grid((n + 63) / 64, num_sets, 1);
+  const dim3 grid((n + 63) / 64, num_sets, row_tiles);
   const int cpg = group / (32 * cs);
   SkGroups gp{};
   gp.row_offsets = row_offsets;
@@ -397,13 +399,20 @@ int launch_q4_gemm_skinny_grouped(const void* x, const int* x_rows, const void* 
   return 0;
 }
 
-// Whether a grouped product takes the kernel above: sets of at most 16 rows and enough column
-// strips over all sets to fill the chip without K slices.
+// Whether a grouped product takes the kernel above: few rows per set -- at most VLA_Q4_SKINNY_ROWS
+// (default 48) in any set and 16 on average, so that second and third weight passes stay the
+// exception -- and enough column strips over all sets to fill the chip without K slices.
 bool q4_skinny_grouped_ok(int max_rows_per_set, int total_rows, int num_sets, int n, int k,
                           int group) {
   int nwv = 0, splits = 0, cs = 0;
-  if (max_rows_per_set < 1 || max_rows_per_set > 16) return false;
-  if (!q4_skinny_shape(max_rows_per_set, n, k, group, &nwv, &splits, &cs)) return false;
+  static const int max_rows = [] {
+    const char* e = getenv("VLA_Q4_SKINNY_ROWS");
+    const int v = (e && *e) ? atoi(e) : 48;
+    return v < 16 ? 16 : v;
+  }();
+  if (max_rows_per_set < 1 || max_rows_per_set > max_rows) return false;
+  if (max_rows_per_set > 16 && total_rows > 16 * num_sets) return false;
+  if (!q4_skinny_shape(1, n, k, group, &nwv, &splits, &cs)) return false;
   if ((int64_t)total_rows * k >= (1ll << 30)) return false;      // 32-bit lane offsets into x
   return (int64_t)((n + 63) / 64) * num_sets > 256;
 }
