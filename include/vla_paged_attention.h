@@ -345,6 +345,14 @@ int vla_q4_gemm_grouped_gather(const void* x, const int* x_rows, const int32_t* 
  * model dtype: `expert_layer(hidden_states).mul_(expert_weights)` and `final.add_(...)` of
  * :141-151, where the experts a token did not choose add exact zeros.  y [pairs, hidden] fp16 /
  * bf16, routing_weights fp32 [num_tokens * top_k], top_k <= 8, hidden a multiple of 8. */
+/* vla_moe_gate_topk: the gate's projection and vla_moe_route_topk in one launch (the reference
+ * runs `self.gate(hidden_states)` as a library GEMM, mixtral_quant.py:130-131; at decode sizes
+ * that GEMM and the separate top-k launch cost more than everything else in the routing glue).
+ * x [num_tokens, hidden], gate [hidden, num_experts] (x @ gate), fp16 / bf16, num_experts 8 or 16,
+ * hidden a multiple of 8; logits = model_dtype(fp32 sums); logits_out (nullable) receives them. */
+int vla_moe_gate_topk(const void* x, const void* gate, int num_tokens, int hidden, int num_experts,
+                      int top_k, float* routing_weights, int64_t* selected_experts,
+                      void* logits_out, int dtype, void* stream);
 int vla_moe_route_topk(const void* router_logits, int num_tokens, int num_experts, int top_k,
                        float* routing_weights, int64_t* selected_experts, int dtype, void* stream);
 int vla_moe_sort_pairs(const int64_t* selected_experts, const int* bucket_of, int num_experts,

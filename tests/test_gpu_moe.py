@@ -92,6 +92,27 @@ def test_moe_route_topk_is_softmax_topk_renormalise(tokens, experts, top_k, dtyp
     assert torch.all(w[:, :-1] >= w[:, 1:]) if top_k > 1 else True
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("tokens,hidden,experts,top_k", [(1, 4096, 8, 2), (16, 4096, 8, 2),
+                                                         (300, 1024, 16, 4), (7, 264, 8, 1)])
+def test_moe_gate_topk_is_the_projection_followed_by_route_topk(tokens, hidden, experts, top_k, dtype):
+    """The router's projection and top-k in one launch: its logits are fp32 sums of x . gate[:, e]
+    rounded to the model dtype (checked against a float64 product within one rounding step of the
+    model dtype), and routing from those logits equals vla_moe_route_topk's bit for bit."""
+    from vllm_legacy_amd import _custom_ops as ops
+    g = torch.Generator(device="cuda").manual_seed(tokens + hidden)
+    x = torch.randn((tokens, hidden), device="cuda", generator=g).to(dtype)
+    gate = (torch.randn((hidden, experts), device="cuda", generator=g) * hidden ** -0.5).to(dtype)
+    w, sel, logits = ops.moe_gate_topk(x, gate, top_k, want_logits=True)
+    exact = x.double() @ gate.double()
+    eps = 2.0 ** -10 if dtype == torch.float16 else 2.0 ** -7
+    assert torch.all((logits.double() - exact).abs() <= eps * exact.abs().clamp(min=1.0))
+    w2, sel2 = ops.moe_route_topk(logits, top_k)
+    assert torch.equal(sel, sel2) and torch.equal(w, w2)
+    w3, sel3 = ops.moe_gate_topk(x, gate, top_k)             # without the logits output
+    assert torch.equal(sel, sel3) and torch.equal(w, w3)
+
+
 @pytest.mark.parametrize("tokens,top_k,experts,local", [(1, 2, 8, 8), (37, 2, 8, 8), (256, 2, 8, 4),
                                                         (1000, 2, 8, 8), (4096, 2, 8, 8),
                                                         (300, 4, 64, 16), (64, 1, 8, 2)])

@@ -555,6 +555,28 @@ def moe_route_topk(router_logits: torch.Tensor, top_k: int):
     return w, sel
 
 
+def moe_gate_topk(hidden_states: torch.Tensor, gate: torch.Tensor, top_k: int,
+                  want_logits: bool = False):
+    """The router in one launch: logits = hidden_states @ gate (fp32 sums rounded to the model
+    dtype), softmax (fp32) -> top_k -> renormalise.  gate [hidden, experts], 8 or 16 experts.
+    Returns (routing_weights fp32 [tokens, top_k], selected_experts int64 [tokens, top_k]) and,
+    with want_logits, the logits."""
+    _require_cuda(hidden_states, gate)
+    assert hidden_states.dtype == gate.dtype and hidden_states.dim() == 2
+    x, g = hidden_states.contiguous(), gate.contiguous()
+    tokens, hidden = x.shape
+    experts = g.shape[1]
+    assert g.shape[0] == hidden
+    w = torch.empty((tokens, top_k), dtype=torch.float32, device=x.device)
+    sel = torch.empty((tokens, top_k), dtype=torch.int64, device=x.device)
+    logits = torch.empty((tokens, experts), dtype=x.dtype, device=x.device) if want_logits else None
+    with torch.cuda.device(x.device):
+        check(_lib.lib().vla_moe_gate_topk(
+            x.data_ptr(), g.data_ptr(), tokens, hidden, experts, top_k, w.data_ptr(),
+            sel.data_ptr(), _ptr(logits), _dt(x), _stream(x.device)), "moe_gate_topk")
+    return (w, sel, logits) if want_logits else (w, sel)
+
+
 def moe_sort_pairs(selected_experts: torch.Tensor, bucket_of: torch.Tensor, num_buckets: int,
                    want_row_bucket: bool = False):
     """Stable bucketing of the (token, choice) pairs of a top-k routing by local expert, on the

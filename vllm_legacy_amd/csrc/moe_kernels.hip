@@ -117,6 +117,76 @@ __global__ __launch_bounds__(256) void moe_route_topk_kernel(
   }
 }
 
+// The router's projection and its top-k in one launch: one workgroup per token computes the NE
+// logits x . gate[:, e] (fp32 sums, rounded to the model dtype as the gate's linear layer rounds
+// its output, mixtral_quant.py:130-131), then wave 0 runs the softmax / top-k / renormalisation of
+// moe_route_topk_kernel on them.  At decode sizes the library GEMM for a [tokens, hidden] x
+// [hidden, 8] product and the separate top-k launch cost 13 + 5 us; this is one small launch.
+// gate is [hidden][NE] (x @ gate); 8 hidden elements per thread and pass.
+template <class S, int NE>
+__global__ __launch_bounds__(256) void moe_gate_topk_kernel(
+    const typename S::T* __restrict__ x, const typename S::T* __restrict__ gate, int hidden,
+    int top_k, float* __restrict__ weights, int64_t* __restrict__ experts,
+    typename S::T* __restrict__ logits_out) {
+  using T = typename S::T;
+  __shared__ float part[4][NE];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t tok = blockIdx.x;
+  float acc[NE];
+#pragma unroll
+  for (int e = 0; e < NE; ++e) acc[e] = 0.f;
+  for (int h = threadIdx.x * 8; h < hidden; h += 256 * 8) {
+    const u32x4 xv = *reinterpret_cast<const u32x4*>(x + tok * hidden + h);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float xf = S::to_f32(__builtin_bit_cast(T, (uint16_t)(xv[j >> 1] >> (16 * (j & 1)))));
+      const T* g = gate + (int64_t)(h + j) * NE;
+#pragma unroll
+      for (int e8 = 0; e8 < NE; e8 += 8) {
+        const u32x4 gv = *reinterpret_cast<const u32x4*>(g + e8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          acc[e8 + e] += xf * S::to_f32(__builtin_bit_cast(T, (uint16_t)(gv[e >> 1] >> (16 * (e & 1)))));
+      }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < NE; ++e) {
+    const float v = wave_sum(acc[e]);
+    if (lane == 0) part[wave][e] = v;
+  }
+  __syncthreads();
+  if (wave != 0) return;
+  const bool has = lane < NE;
+  float xl = -INFINITY;
+  if (has) {
+    const T r = S::from_f32(part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane]);
+    if (logits_out) logits_out[tok * NE + lane] = r;
+    xl = S::to_f32(r);
+  }
+  const float mx = wave_max(xl);
+  const float ex = has ? expf(xl - mx) : 0.f;
+  const float p = ex / wave_sum(ex);
+  float v = has ? p : -INFINITY;
+  float chosen_w = 0.f, total = 0.f;    // lane j keeps the j-th choice
+  int chosen_e = 0;
+  for (int j = 0; j < top_k; ++j) {
+    const float best = wave_max(v);
+    const uint64_t at = __ballot(v == best);
+    const int idx = __ffsll((unsigned long long)at) - 1;
+    if (lane == j) {
+      chosen_w = best;
+      chosen_e = idx;
+    }
+    total += best;
+    if (lane == idx) v = -INFINITY;
+  }
+  if (lane < top_k) {
+    weights[tok * top_k + lane] = chosen_w / total;
+    experts[tok * top_k + lane] = chosen_e;
+  }
+}
+
 // One workgroup per token; 8 elements (16 bytes) per lane and pass.
 template <class S, int MAXK>
 __global__ __launch_bounds__(256) void moe_combine_kernel(
@@ -213,6 +283,32 @@ extern "C" int vla_moe_route_topk(const void* router_logits, int num_tokens, int
                        routing_weights, selected_experts);
   else
     return VLA_ERR_DTYPE;
+  VLA_HIP_CHECK(hipGetLastError());
+  return VLA_OK;
+}
+
+extern "C" int vla_moe_gate_topk(const void* x, const void* gate, int num_tokens, int hidden,
+                                 int num_experts, int top_k, float* routing_weights,
+                                 int64_t* selected_experts, void* logits_out, int dtype,
+                                 void* stream) {
+  (void)hipGetLastError();
+  if (num_tokens == 0) return VLA_OK;
+  if (!x || !gate || !routing_weights || !selected_experts || num_tokens < 0 || hidden <= 0 ||
+      hidden % 8 || (num_experts != 8 && num_experts != 16) || top_k <= 0 || top_k > num_experts ||
+      ((uintptr_t)x % 16) || ((uintptr_t)gate % 16))
+    return VLA_ERR_ARG;
+  if (dtype != VLA_F16 && dtype != VLA_BF16) return VLA_ERR_DTYPE;
+  hipStream_t s = (hipStream_t)stream;
+#define VLA_GATE(S_, NE_)                                                                        \
+  hipLaunchKernelGGL((moe_gate_topk_kernel<S_, NE_>), dim3(num_tokens), dim3(256), 0, s,          \
+                     (const typename S_::T*)x, (const typename S_::T*)gate, hidden, top_k,       \
+                     routing_weights, selected_experts, (typename S_::T*)logits_out)
+  if (dtype == VLA_F16) {
+    if (num_experts == 8) VLA_GATE(F16, 8); else VLA_GATE(F16, 16);
+  } else {
+    if (num_experts == 8) VLA_GATE(BF16, 8); else VLA_GATE(BF16, 16);
+  }
+#undef VLA_GATE
   VLA_HIP_CHECK(hipGetLastError());
   return VLA_OK;
 }

@@ -70,7 +70,16 @@ class QuantMixtralMoE(nn.Module):
             experts.append(e if idx in self.expert_indicies else None)
         self.experts = nn.ModuleList([e if e is not None else nn.Identity() for e in experts])
 
+    # up to this many tokens the router's projection and top-k run as one small launch; above,
+    # the library GEMM's throughput wins over one workgroup per token
+    GATE_FUSED_MAX_TOKENS = 1024
+
     def route(self, hidden_states: torch.Tensor):
+        if (hidden_states.is_cuda and self.num_total_experts in (8, 16) and
+                hidden_states.dtype in (torch.float16, torch.bfloat16) and
+                hidden_states.shape[0] <= self.GATE_FUSED_MAX_TOKENS and
+                hidden_states.shape[1] % 8 == 0 and self.gate.is_contiguous()):
+            return ops.moe_gate_topk(hidden_states, self.gate, self.top_k)
         router_logits = torch.matmul(hidden_states, self.gate)
         if self.num_total_experts <= 64 and router_logits.is_cuda:
             # softmax, top-k and renormalisation in one launch (same values as the lines below)
