@@ -1413,6 +1413,9 @@ static Q4Shape pick_shape(int m, int n, int k, int group) {
       want = b;
     }
     if (got == 4 && (d == 1 || d == 2 || d == 4)) kw = d;
+    // 32- and 64-row tiles exist with four waves (128 columns) only: an override that shrinks
+    // the tile must not leave the 256-column grid of the shape it replaced
+    if (s.mt != 4) s.nw = 4;
   }
   const int unit = group > TK ? group : TK;  // a split must hold whole groups and whole K steps
   while (want > 1 && (k % (want * unit)) != 0) --want;
