@@ -180,3 +180,34 @@ def test_grouped_small_sets_equal_the_tiled_grouped_launch(ops):
     torch.cuda.synchronize()
     np.testing.assert_allclose(small.float().cpu().numpy(), tiled.float().cpu().numpy(), rtol=3e-3,
                                atol=4e-3)
+
+
+def test_random_small_shapes(ops):
+    """Twenty random (batch, K, N, group) draws within the kernel's contract -- N a multiple of 8,
+    K a multiple of 64 and of the group, groups of 32 / 64 / 128 / K -- against the oracle, AWQ and
+    GPTQ zero conventions alternating."""
+    rng = np.random.default_rng(2024)
+    none = torch.empty(0, dtype=torch.int32, device="cuda")
+    for case in range(20):
+        m = int(rng.integers(1, 17))
+        k = 64 * int(rng.integers(1, 33))
+        n = 8 * int(rng.integers(1, 76))
+        groups = [g for g in (32, 64, 128, k) if k % g == 0]
+        group = int(groups[int(rng.integers(0, len(groups)))])
+        x = O.to_bits(rng.uniform(-1, 1, (m, k)).astype(np.float32), O.DT_F16)
+        if case % 2 == 0:
+            qw, qz, sc = _awq_weights(rng, k, n, group)
+            pw, pz = ops.awq_repack(_cuda(qw), _cuda(qz))
+            got = ops.q4_gemm_packed(_cuda(x, O.DT_F16), pw, pz, _cuda(sc, O.DT_F16), 0)
+            w = O.awq_dequantize(qw, sc, qz)
+        else:
+            qw, qz, sc = _gptq_weights(rng, k, n, group)
+            gq = _cuda(qw.copy())
+            ops.gptq_shuffle(gq, none, 4)
+            got = ops.gptq_gemm(_cuda(x, O.DT_F16), gq, _cuda(qz), _cuda(sc, O.DT_F16), none, True, 4)
+            w = O.gptq_dequantize(qw, qz, sc)
+        torch.cuda.synchronize()
+        assert got.shape == (m, n), (case, m, k, n, group)
+        want = O.from_bits(O.gemm_f16(x, w), O.DT_F16)
+        np.testing.assert_allclose(got.float().cpu().numpy(), want, rtol=2e-3, atol=2e-3,
+                                   err_msg=f"case {case}: m={m} k={k} n={n} group={group}")
