@@ -421,6 +421,17 @@ int vla_ar_error_count_async(void* ctx, int* host_out, void* stream);
 
 /* ---- fused forms (same results as the separate calls, fewer launches) ----------------------- */
 
+/* No counterpart in the reference (its MLP runs the projection and SiluAndMul as two ops,
+ * vllm/model_executor/models/llama.py:76-79, csrc/activation_kernels.cu:14-33).  For decode batches
+ * of at most 16 rows and a [gate | up] weight wide enough to run unsliced: out [m, n / 2] =
+ * silu(gate) * up computed in the product's epilogue, one launch instead of two, the bits of
+ * vla_q4_gemm_packed followed by vla_silu_and_mul.  vla_q4_gemm_silu_and_mul_supported says
+ * whether a shape is taken (1 / 0); other shapes return VLA_ERR_QUANT_SHAPE and launch nothing. */
+int vla_q4_gemm_silu_and_mul_supported(int m, int n, int k, int group);
+int vla_q4_gemm_packed_silu_and_mul(const void* x, const int32_t* qweight, const int32_t* qzeros,
+                                    const void* scales, void* out, int m, int n, int k, int group,
+                                    int zero_offset, void* stream);
+
 /* vla_q4_gemm_packed without its reduction launch: when the product was split along K,
  * *num_slabs (> 1) fp32 slabs [num_slabs][m][n] are left in `workspace` for a consumer below to
  * sum; *num_slabs == 0 means the result went straight to `out`.  The reference has no such

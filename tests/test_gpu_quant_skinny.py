@@ -211,3 +211,34 @@ def test_random_small_shapes(ops):
         want = O.from_bits(O.gemm_f16(x, w), O.DT_F16)
         np.testing.assert_allclose(got.float().cpu().numpy(), want, rtol=2e-3, atol=2e-3,
                                    err_msg=f"case {case}: m={m} k={k} n={n} group={group}")
+
+
+# ---------------------------------------------------------------- product + SiluAndMul in one launch
+@pytest.mark.parametrize("m", [1, 7, 16])
+@pytest.mark.parametrize("k,n,group,zo", [(4096, 28672, 128, 0), (512, 16400, 128, 0),
+                                          (256, 16448, 64, 1), (1024, 16384 + 64, 32, 1)])
+def test_gate_up_product_with_silu_and_mul_in_its_epilogue(ops, m, k, n, group, zo):
+    """out = silu(gate) * up from the product's epilogue equals the product followed by
+    silu_and_mul bit for bit (halves of 8200 / 8224 / 8224 columns end inside a workgroup's 32)."""
+    rng = np.random.default_rng(m + k + n)
+    qw, qz, sc = _awq_weights(rng, k, n, group)          # k-packing is the same for both kinds
+    pw, pz = ops.awq_repack(_cuda(qw), _cuda(qz))
+    x = _cuda(O.to_bits(rng.uniform(-1, 1, (m, k)).astype(np.float32), O.DT_F16), O.DT_F16)
+    scd = _cuda(sc, O.DT_F16) * 4                          # gate values of a few units
+    fused = ops.q4_gemm_packed_silu_and_mul(x, pw, pz, scd, zo)
+    assert fused is not None and fused.shape == (m, n // 2)
+    prod = ops.q4_gemm_packed(x, pw, pz, scd, zo)
+    two = torch.empty((m, n // 2), dtype=torch.float16, device="cuda")
+    ops.silu_and_mul(two, prod)
+    torch.cuda.synchronize()
+    assert torch.equal(fused.view(torch.int16), two.view(torch.int16))
+    assert fused.float().abs().max().item() > 0.05        # not a product of zeros
+
+
+def test_gate_up_with_silu_is_refused_for_shapes_the_kernel_does_not_take(ops):
+    rng = np.random.default_rng(1)
+    for m, k, n in ((1, 512, 256), (17, 512, 16400), (4, 4096, 6144)):
+        qw, qz, sc = _awq_weights(rng, k, n, 128)
+        pw, pz = ops.awq_repack(_cuda(qw), _cuda(qz))
+        x = _cuda(O.to_bits(rng.uniform(-1, 1, (m, k)).astype(np.float32), O.DT_F16), O.DT_F16)
+        assert ops.q4_gemm_packed_silu_and_mul(x, pw, pz, _cuda(sc, O.DT_F16), 0) is None

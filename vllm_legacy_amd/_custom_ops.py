@@ -668,6 +668,29 @@ def q4_gemm_packed_partial(x: torch.Tensor, qweight: torch.Tensor, qzeros: torch
     return out
 
 
+def q4_gemm_packed_silu_and_mul(x: torch.Tensor, qweight: torch.Tensor, qzeros: torch.Tensor,
+                                scales: torch.Tensor, zero_offset: int) -> Optional[torch.Tensor]:
+    """silu(x @ W[:, :n/2]) * (x @ W[:, n/2:]) in one launch for a k-packed [gate | up] weight
+    and a decode batch of at most 16 rows; None when the library does not take the shape (the
+    caller then runs q4_gemm_packed_partial and silu_and_mul, which give the same bits)."""
+    _require_cuda(x, qweight, qzeros, scales)
+    if x.dtype != torch.float16 or x.dim() != 2:
+        return None
+    m, k = x.shape
+    n = qweight.shape[1]
+    group = k // qzeros.shape[0]
+    L = _lib.lib()
+    if m == 0 or not L.vla_q4_gemm_silu_and_mul_supported(m, n, k, group):
+        return None
+    x = x.contiguous()
+    out = torch.empty((m, n // 2), dtype=x.dtype, device=x.device)
+    with torch.cuda.device(x.device):
+        check(L.vla_q4_gemm_packed_silu_and_mul(
+            x.data_ptr(), qweight.data_ptr(), qzeros.data_ptr(), scales.data_ptr(), out.data_ptr(),
+            m, n, k, group, zero_offset, _stream(x.device)), "q4_gemm_packed_silu_and_mul")
+    return out
+
+
 def rotary_reshape_and_cache(positions: torch.Tensor, query: torch.Tensor, key: torch.Tensor,
                              value: torch.Tensor, head_size: int, cos_sin_cache: torch.Tensor,
                              is_neox: bool, key_cache, value_cache, slot_mapping: torch.Tensor,

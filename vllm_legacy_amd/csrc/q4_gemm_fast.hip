@@ -1309,6 +1309,10 @@ bool q4_skinny_shape(int m, int n, int k, int group, int* nwv, int* splits, int*
 int launch_q4_gemm_skinny(const void* x, const void* qw, const void* qz, const void* scales,
                           void* dst, int m, int n, int k, int group, int zero_offset, int nwv,
                           int splits, int cs, hipStream_t s);
+bool q4_skinny_silu_ok(int m, int n, int k, int group);
+int launch_q4_gemm_skinny_silu(const void* x, const void* qw, const void* qz, const void* scales,
+                               void* out, int m, int n, int k, int group, int zero_offset,
+                               hipStream_t s);
 bool q4_skinny_grouped_ok(int max_rows_per_set, int total_rows, int num_sets, int n, int k,
                           int group);
 int launch_q4_gemm_skinny_grouped(const void* x, const int* x_rows, const void* qw, const void* qz,
@@ -1621,6 +1625,32 @@ extern "C" int vla_q4_gemm_packed_partial(const void* x, const int32_t* qweight,
   if (!num_slabs) return VLA_ERR_ARG;
   return q4_gemm_run(x, qweight, qzeros, scales, out, m, n, k, group, zero_offset, workspace,
                      workspace_bytes, stream, false, num_slabs);
+}
+
+// x [m, k] . [gate | up] (k-packed, n columns) -> silu(gate) * up [m, n / 2] in one launch, for
+// the shapes the small-batch kernel runs unsliced (vla_q4_gemm_silu_and_mul_supported; the
+// caller otherwise runs the product and the activation as two launches, which give the same bits).
+extern "C" int vla_q4_gemm_silu_and_mul_supported(int m, int n, int k, int group) {
+  if (m <= 0 || n <= 0 || k <= 0 || group <= 0 || k % TK || group % 32 || k % group) return 0;
+  return q4_skinny_silu_ok(m, n, k, group) ? 1 : 0;
+}
+
+extern "C" int vla_q4_gemm_packed_silu_and_mul(const void* x, const int32_t* qweight,
+                                               const int32_t* qzeros, const void* scales,
+                                               void* out, int m, int n, int k, int group,
+                                               int zero_offset, void* stream) {
+  (void)hipGetLastError();
+  if (!x || !qweight || !qzeros || !scales || !out || m < 0) return VLA_ERR_ARG;
+  if (n % 16 || k % TK || group <= 0 || group % 32 || k % group ||
+      (zero_offset != 0 && zero_offset != 1))
+    return VLA_ERR_QUANT_SHAPE;
+  if (((uintptr_t)x % 16) || ((uintptr_t)out % 8)) return VLA_ERR_ARG;
+  if (m == 0) return VLA_OK;
+  if (!q4_skinny_silu_ok(m, n, k, group)) return VLA_ERR_QUANT_SHAPE;
+  launch_q4_gemm_skinny_silu(x, qweight, qzeros, scales, out, m, n, k, group, zero_offset,
+                             (hipStream_t)stream);
+  VLA_HIP_CHECK(hipGetLastError());
+  return VLA_OK;
 }
 
 extern "C" int vla_awq_repack(const int32_t* qweight, const int32_t* qzeros, int32_t* out_qweight,

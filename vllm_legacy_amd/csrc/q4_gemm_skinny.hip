@@ -19,7 +19,8 @@
 //    the loop, every wave runs on its own loads alone.
 //  * zeros and scales are fetched once per chunk of CS steps that lies inside one group.
 //  * a workgroup is NWV waves on the SAME 64 columns, each walking its own part of the
-//    workgroup's K range; their sums meet through LDS once, in wave order.  Layers with few
+//    workgroup's K range; their sums meet through LDS once, in wave order (the first four waves
+//    each finish and store a quarter of the tile).  Layers with few
 //    columns are also cut into K slices across workgroups (fp32 slabs, as the larger kernels).
 //
 // Measured and not taken: batches of 17-32 rows on the same kernel with a second MFMA per
@@ -62,14 +63,21 @@ struct SkGroups {
   int64_t w_stride, z_stride, s_stride;      // elements between consecutive sets
 };
 
-template <int ZOFF, bool SPLIT, int NWV, int CS, int NB, bool GROUPED = false>
+// SILU: the product is a [gate | up] pair of halves (a SwiGLU MLP's first projection, n / 2
+// columns each) and the launch writes silu(gate) * up, [M, n / 2], instead of the product: a
+// workgroup takes 32 gate columns (lanes c < 8) and the 32 up columns that pair with them (lanes
+// c >= 8), so after the MFMAs lane (c, g < 2) holds 16 gate values and lane (c, g + 2) the matching
+// up values; one cross-half exchange later the activation runs in the epilogue with the
+// arithmetic of the stand-alone kernel (both halves rounded to fp16 first, silu rounded, product
+// rounded: csrc/activation_kernels.cu:14-33).  Unsliced launches only.
+template <int ZOFF, bool SPLIT, int NWV, int CS, int NB, bool GROUPED = false, bool SILU = false>
 __global__ __launch_bounds__(64 * NWV) void q4_gemm_skinny_kernel(
     const _Float16* __restrict__ x, const uint32_t* __restrict__ qw,
     const uint32_t* __restrict__ qz, const _Float16* __restrict__ scales, void* __restrict__ outp,
     int m, int n, int k, int group_size, int k_per_split, int chunks_per_group,
     SkGroups gp = SkGroups{}) {
   static_assert(NB == 2 || NB == 3, "ring depth");
-  __shared__ f32x4 red[(NWV > 1 ? NWV - 1 : 1) * 4 * 64];
+  __shared__ float red[NWV * 16 * 64];         // [wave][i][j][lane]: every wave's partial sums
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -87,9 +95,19 @@ __global__ __launch_bounds__(64 * NWV) void q4_gemm_skinny_kernel(
     qz += (int64_t)set * gp.z_stride;
     scales += (int64_t)set * gp.s_stride;
   }
+  static_assert(!SILU || (!SPLIT && !GROUPED), "the fused activation needs the finished product");
   const int n0 = blockIdx.x * 64;
-  const int col = n0 + 4 * c;
-  const int colc = col < n ? col : 0;          // clamped: loads stay in bounds, result unused
+  const int half_n = n >> 1;                   // SILU: n % 16 == 0 (host)
+  const int g0 = blockIdx.x * 32;              // SILU: first gate column of this workgroup
+  int col, col_end;
+  if constexpr (SILU) {
+    col = c < 8 ? g0 + 4 * c : half_n + g0 + 4 * (c - 8);
+    col_end = c < 8 ? half_n : n;
+  } else {
+    col = n0 + 4 * c;
+    col_end = n;
+  }
+  const int colc = col < col_end ? col : 0;    // clamped: loads stay in bounds, result unused
 
   // this wave's chunks of the workgroup's K slice
   constexpr int CK = 32 * CS;
@@ -231,36 +249,66 @@ __global__ __launch_bounds__(64 * NWV) void q4_gemm_skinny_kernel(
     if (t < nch) compute(b0);
   }
 
-  // ---- the K parts of the workgroup meet in LDS; wave 0 adds them in wave order
+  // ---- the K parts of the workgroup meet in LDS: every wave parks its sums, then wave i (of the
+  // first four) adds up, in wave order, the quads i of all lanes -- acc[0..3][i], four adjacent
+  // columns -- and stores them: the tail of the launch is shared by four waves
+  float q[4];                                  // this wave's quad: q[j] = sum of acc[j][qi]
+  const int qi = NWV > 1 ? wave : 0;           // which quad this wave finishes (NWV = 1: all four)
   if constexpr (NWV > 1) {
-    if (wave > 0) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) red[((wave - 1) * 4 + j) * 64 + lane] = acc[j];
-    }
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) red[((wave * 4 + i) * 4 + j) * 64 + lane] = acc[j][i];
     __syncthreads();
-    if (wave != 0) return;
+    if (wave >= 4) return;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) q[j] = red[((0 * 4 + qi) * 4 + j) * 64 + lane];
 #pragma unroll
     for (int w = 1; w < NWV; ++w)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc[j] += red[((w - 1) * 4 + j) * 64 + lane];
+      for (int j = 0; j < 4; ++j) q[j] += red[((w * 4 + qi) * 4 + j) * 64 + lane];
   }
-
-  // ---- epilogue: MFMA j's row r is column 4 r + j of the strip, so lane (c, g) holds, for x row
-  // c, the 16 adjacent columns n0 + 16 g + 4 i + j in acc[j][i]
-  if (c >= m) return;
+  // lane (c, g) now holds, for x row c, the four adjacent columns 16 g + 4 i + (0..3) of the strip
+  // (MFMA j's row r is column 4 r + j)
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int oc = n0 + 16 * g + 4 * i;
-    if (oc >= n) continue;                       // n % 8 == 0: a quad is inside or outside
-    if constexpr (SPLIT) {
-      float* dst = reinterpret_cast<float*>(outp) +
-                   ((int64_t)blockIdx.z * slab_rows + row_base + c) * n + oc;
-      *reinterpret_cast<f32x4*>(dst) = f32x4{acc[0][i], acc[1][i], acc[2][i], acc[3][i]};
+  for (int i0 = 0; i0 < (NWV > 1 ? 1 : 4); ++i0) {
+    const int i = NWV > 1 ? qi : i0;
+    if constexpr (NWV == 1) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) q[j] = acc[j][i0];
+    }
+    if constexpr (SILU) {
+      // g < 2: gate columns g0 + 16 g + 4 i + j; g >= 2: the up columns that pair with the gate
+      // columns of lane (c, g - 2) = lane - 32
+      float up[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) up[j] = __shfl(q[j], (lane + 32) & 63, 64);
+      const int oc = g0 + 16 * g + 4 * i;
+      if (g < 2 && c < m && oc < half_n) {
+        _Float16 r[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float xg = (float)(_Float16)q[j], yu = (float)(_Float16)up[j];
+          const float sl = (float)(_Float16)(xg / (1.0f + expf(-xg)));
+          r[j] = (_Float16)(sl * yu);
+        }
+        _Float16* dst = reinterpret_cast<_Float16*>(outp) + (int64_t)c * half_n + oc;
+        *reinterpret_cast<u32x2*>(dst) = u32x2{sk_u32(f16x2{r[0], r[1]}), sk_u32(f16x2{r[2], r[3]})};
+      }
     } else {
-      _Float16* dst = reinterpret_cast<_Float16*>(outp) + (int64_t)(row_base + c) * n + oc;
-      const f16x2 lo = {(_Float16)acc[0][i], (_Float16)acc[1][i]};
-      const f16x2 hi = {(_Float16)acc[2][i], (_Float16)acc[3][i]};
-      *reinterpret_cast<u32x2*>(dst) = u32x2{sk_u32(lo), sk_u32(hi)};
+      const int oc = n0 + 16 * g + 4 * i;
+      if (c < m && oc < n) {                     // n % 8 == 0: a quad is inside or outside
+        if constexpr (SPLIT) {
+          float* dst = reinterpret_cast<float*>(outp) +
+                       ((int64_t)blockIdx.z * slab_rows + row_base + c) * n + oc;
+          *reinterpret_cast<f32x4*>(dst) = f32x4{q[0], q[1], q[2], q[3]};
+        } else {
+          _Float16* dst = reinterpret_cast<_Float16*>(outp) + (int64_t)(row_base + c) * n + oc;
+          const f16x2 lo = {(_Float16)q[0], (_Float16)q[1]};
+          const f16x2 hi = {(_Float16)q[2], (_Float16)q[3]};
+          *reinterpret_cast<u32x2*>(dst) = u32x2{sk_u32(lo), sk_u32(hi)};
+        }
+      }
     }
   }
 }
@@ -366,6 +414,33 @@ int launch_q4_gemm_skinny(const void* x, const void* qw, const void* qz, const v
 #undef VLA_SK_W
 #undef VLA_SK_NB
 #undef VLA_SK_ARGS
+  return 0;
+}
+
+// The SwiGLU form (see SILU): whether a [gate | up] product of this shape takes it -- wide enough
+// to run unsliced with four waves per workgroup, halves that split into whole 8-column groups.
+bool q4_skinny_silu_ok(int m, int n, int k, int group) {
+  int nwv = 0, splits = 0, cs = 0;
+  if (n % 16 || !q4_skinny_shape(m, n, k, group, &nwv, &splits, &cs)) return false;
+  return splits == 1 && nwv == 4 && (cs == 4 || cs == 1);
+}
+
+int launch_q4_gemm_skinny_silu(const void* x, const void* qw, const void* qz, const void* scales,
+                               void* out, int m, int n, int k, int group, int zero_offset,
+                               hipStream_t s) {
+  const int cs = group % 128 == 0 ? 4 : 1;
+  const dim3 grid((n / 2 + 31) / 32, 1, 1);
+  const int cpg = group / (32 * cs);
+#define VLA_SKS(Z, C)                                                                            \
+  hipLaunchKernelGGL((q4_gemm_skinny_kernel<Z, false, 4, C, 3, false, true>), grid, dim3(256), 0,  \
+                     s, (const _Float16*)x, (const uint32_t*)qw, (const uint32_t*)qz,            \
+                     (const _Float16*)scales, out, m, n, k, group, k, cpg)
+  if (zero_offset == 0) {
+    if (cs == 4) VLA_SKS(0, 4); else VLA_SKS(0, 1);
+  } else {
+    if (cs == 4) VLA_SKS(1, 4); else VLA_SKS(1, 1);
+  }
+#undef VLA_SKS
   return 0;
 }
 

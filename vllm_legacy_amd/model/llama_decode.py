@@ -13,6 +13,8 @@ decode-step benchmark and the tensor-parallel tests, not to load models.
 from dataclasses import dataclass
 from typing import List, Optional
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -69,6 +71,10 @@ class LlamaConfig:
                            vocab_size=1024, max_position_embeddings=512)
 
 
+# VLA_FUSE_SILU=0 keeps the gate_up product and SiluAndMul as two launches at every batch size
+_FUSE_SILU = os.environ.get("VLA_FUSE_SILU", "1") != "0"
+
+
 class QuantLinear(nn.Module):
     """Column- or row-parallel int4 linear with random weights in the checkpoint layout."""
 
@@ -113,6 +119,14 @@ class QuantLinear(nn.Module):
         if defer_reduce and hasattr(self.method, "apply_partial"):
             return self.method.apply_partial(self, x)
         return self.method.apply(self, x)
+
+    def forward_silu_and_mul(self, x: torch.Tensor):
+        """SiluAndMul(forward(x)) of a [gate | up] projection as one launch, or None when the
+        quantization method has no such form for this batch (the caller runs the two steps)."""
+        if (_FUSE_SILU and self.method is not None and
+                hasattr(self.method, "apply_silu_and_mul")):
+            return self.method.apply_silu_and_mul(self, x)
+        return None
 
 
 class LlamaDecodeLayer(nn.Module):
@@ -190,8 +204,10 @@ class LlamaDecodeLayer(nn.Module):
             # router, routed experts and the block's own all-reduce (mixtral_quant.py:129-156)
             return self.block_sparse_moe(hidden), residual
         # gate_up is column-parallel: whatever K slices it made are summed by the activation
-        hidden = self.down_proj(self.act_fn(self.gate_up_proj(hidden, defer_reduce=True), dt),
-                                defer_reduce=fuse)
+        act = self.gate_up_proj.forward_silu_and_mul(hidden)   # small decode batches: one launch
+        if act is None:
+            act = self.act_fn(self.gate_up_proj(hidden, defer_reduce=True), dt)
+        hidden = self.down_proj(act, defer_reduce=fuse)
         hidden = PendingAllReduce(hidden) if fuse_norm else tensor_model_parallel_all_reduce(hidden, dt)
         return hidden, residual
 

@@ -65,6 +65,17 @@ class AWQLinearMethod:
                                                          dtype=params_dtype, device=device),
                                              requires_grad=False))
 
+    def apply_silu_and_mul(self, layer: torch.nn.Module, x: torch.Tensor):
+        """For a [gate | up] projection: SiluAndMul(apply(x)) in one launch where the library has
+        one (decode batches of at most 16 rows, wide layers), else None."""
+        if x.dim() != 2 or x.shape[1] % 64 != 0 or x.shape[0] > 16:
+            return None
+        packed = getattr(layer, "_k_packed", None)
+        if packed is None:
+            packed = ops.awq_repack(layer.qweight, layer.qzeros)
+            layer._k_packed = packed
+        return ops.q4_gemm_packed_silu_and_mul(x, packed[0], packed[1], layer.scales, 0)
+
     def apply_partial(self, layer: torch.nn.Module, x: torch.Tensor):
         """apply() that may return the unreduced split-K slabs (ops.SplitKSlabs) for a fused
         consumer instead of the finished [tokens, out] matrix.  2-D input, no bias."""
