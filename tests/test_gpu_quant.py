@@ -308,3 +308,42 @@ def test_grouped_gemm_matches_per_set_products(ops, ic, oc, counts, tail):
             np.testing.assert_allclose(got[start:start + c], O.from_bits(want, O.DT_F16), rtol=3e-3, atol=4e-3)
         start += c
     assert not got[start:].any()
+
+
+@pytest.mark.parametrize("desc_act", [False, True])
+@pytest.mark.parametrize("m,k,n", [(256, 8192, 1280), (5, 1024, 8192), (9, 512, 16400)])
+def test_gptq_linear_method_partial_and_fused_forms_equal_apply(ops, desc_act, m, k, n):
+    """GPTQLinearMethod.apply_partial (unreduced split-K slabs for a fused consumer) and
+    apply_silu_and_mul (the activation in the product's epilogue) give the bits of apply()
+    followed by the reduction / by SiluAndMul."""
+    from vllm_legacy_amd.quantization.gptq import GPTQConfig, GPTQLinearMethod
+    rng = np.random.default_rng(m + k + n)
+    group = 128
+    qw, qz, sc = _gptq_weights(rng, k, n, group)
+    x = _cuda(O.to_bits(rng.uniform(-1, 1, (m, k)).astype(np.float32), O.DT_F16), O.DT_F16)
+
+    def make():
+        layer = torch.nn.Module()
+        meth = GPTQLinearMethod(GPTQConfig(4, group, desc_act))
+        meth.create_weights(layer, k, [n], k, n, torch.float16, device="cuda")
+        layer.qweight.data, layer.qzeros.data = _cuda(qw.copy()), _cuda(qz)
+        layer.scales.data = _cuda(sc, O.DT_F16) * 4
+        if desc_act:
+            perm = np.random.default_rng(7).permutation(k)
+            layer.g_idx.data = torch.from_numpy((perm // group).astype(np.int32)).cuda()
+        return layer, meth
+    layer, meth = make()
+    want = meth.apply(layer, x)
+    layer2, meth2 = make()
+    part = meth2.apply_partial(layer2, x)
+    got = part.reduce() if isinstance(part, ops.SplitKSlabs) else part
+    torch.cuda.synchronize()
+    assert torch.equal(got.view(torch.int16), want.view(torch.int16))
+    act = meth2.apply_silu_and_mul(layer2, x)
+    if m <= 16 and n == 16400:
+        assert act is not None
+    if act is not None:
+        two = torch.empty((m, n // 2), dtype=torch.float16, device="cuda")
+        ops.silu_and_mul(two, want)
+        torch.cuda.synchronize()
+        assert torch.equal(act.view(torch.int16), two.view(torch.int16))

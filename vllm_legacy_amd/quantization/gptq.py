@@ -75,10 +75,8 @@ class GPTQLinearMethod:
                                                          device=device), requires_grad=False))
         layer.exllama_state = state
 
-    def apply(self, layer: torch.nn.Module, x: torch.Tensor,
-              bias: Optional[torch.Tensor] = None) -> torch.Tensor:
-        out_shape = x.shape[:-1] + (layer.qweight.shape[-1], )
-        x2 = x.reshape(-1, x.shape[-1])
+    def _shuffle_once(self, layer: torch.nn.Module) -> None:
+        """First use of an exllama layer: the one-time weight shuffle (gptq.py:209-217)."""
         if layer.exllama_state == ExllamaState.UNINITIALIZED:
             if self.quant_config.desc_act:
                 layer.g_idx.data = torch.argsort(layer.g_idx).to(torch.int)
@@ -86,6 +84,42 @@ class GPTQLinearMethod:
                 layer.g_idx.data = torch.empty((0, ), dtype=torch.int32, device=layer.g_idx.device)
             layer.exllama_state = ExllamaState.READY
             ops.gptq_shuffle(layer.qweight, layer.g_idx, self.quant_config.weight_bits)
+
+    def _k_packed_input(self, layer: torch.nn.Module, x: torch.Tensor):
+        """x as the k-packed MFMA kernels want it (columns in the shuffled weight's row order), or
+        None when this layer does not run on them."""
+        if (x.dim() != 2 or x.dtype != torch.float16 or self.quant_config.weight_bits != 4 or
+                layer.exllama_state == ExllamaState.UNUSED or x.shape[1] % 64 != 0 or
+                (x.shape[1] // layer.qzeros.shape[0]) % 32 != 0):
+            return None
+        self._shuffle_once(layer)
+        if layer.exllama_state != ExllamaState.READY:
+            return None
+        return x.index_select(1, layer.g_idx) if layer.g_idx.numel() > 0 else x
+
+    def apply_partial(self, layer: torch.nn.Module, x: torch.Tensor):
+        """apply() that may return the unreduced split-K slabs (ops.SplitKSlabs) for a fused
+        consumer instead of the finished [tokens, out] matrix.  2-D input, no bias."""
+        xk = self._k_packed_input(layer, x)
+        if xk is None:
+            return self.apply(layer, x)
+        return ops.q4_gemm_packed_partial(xk, layer.qweight, layer.qzeros, layer.scales, 1)
+
+    def apply_silu_and_mul(self, layer: torch.nn.Module, x: torch.Tensor):
+        """For a [gate | up] projection: SiluAndMul(apply(x)) in one launch where the library has
+        one (decode batches of at most 16 rows, wide layers), else None."""
+        if x.dim() != 2 or x.shape[0] > 16:
+            return None
+        xk = self._k_packed_input(layer, x)
+        if xk is None:
+            return None
+        return ops.q4_gemm_packed_silu_and_mul(xk, layer.qweight, layer.qzeros, layer.scales, 1)
+
+    def apply(self, layer: torch.nn.Module, x: torch.Tensor,
+              bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+        out_shape = x.shape[:-1] + (layer.qweight.shape[-1], )
+        x2 = x.reshape(-1, x.shape[-1])
+        self._shuffle_once(layer)
         out = ops.gptq_gemm(x2, layer.qweight, layer.qzeros, layer.scales, layer.g_idx,
                             layer.exllama_state == ExllamaState.READY,
                             self.quant_config.weight_bits)
