@@ -68,14 +68,14 @@ struct Vec16 {  // 16 bytes of model-dtype elements
 // loads what the first has just stored, a round trip through L2 that a decode batch of a few
 // tokens (one workgroup each, nothing else in flight) waits out in full.
 template <class S, bool FUSED, int KEEP>
-__global__ __launch_bounds__(256) void rms_norm_kernel(typename S::T* __restrict__ out,
+__global__ __launch_bounds__(1024) void rms_norm_kernel(typename S::T* __restrict__ out,
                                                        typename S::T* __restrict__ input,
                                                        typename S::T* __restrict__ residual,
                                                        const typename S::T* __restrict__ weight,
                                                        float eps, int hidden) {
   using V = Vec16<S>;
   constexpr int N = V::N;
-  __shared__ float red[4];
+  __shared__ float red[16];
   const int64_t base = (int64_t)blockIdx.x * hidden;
   float var = 0.f;
   if constexpr (KEEP > 0) {
@@ -210,9 +210,13 @@ extern "C" int vla_rms_norm(void* out, const void* input, const void* weight, fl
   if (!vec_ok(out, hidden_size, dtype) || !vec_ok(input, hidden_size, dtype) ||
       !vec_ok(weight, hidden_size, dtype))
     return VLA_ERR_ARG;
-  const bool keep = hidden_size <= 2 * 256 * (dtype == VLA_F32 ? 4 : 8);
+  // one 16-byte vector per thread and pass, up to 1024 threads: a row of 8192 16-bit elements
+  // (Llama-3-70B) is one pass of one workgroup instead of four passes of 256 threads
+  const int vecs = hidden_size / (dtype == VLA_F32 ? 4 : 8);
+  const int threads = vecs >= 1024 ? 1024 : ((vecs + 63) / 64) * 64;
+  const bool keep = vecs <= 2 * threads;
 #define VLA_RMS(KEEP_)                                                                          \
-  hipLaunchKernelGGL((rms_norm_kernel<S, false, KEEP_>), dim3(num_tokens), dim3(256), 0,         \
+  hipLaunchKernelGGL((rms_norm_kernel<S, false, KEEP_>), dim3(num_tokens), dim3(threads), 0,     \
                      (hipStream_t)stream, (typename S::T*)out, (typename S::T*)input,            \
                      (typename S::T*)nullptr, (const typename S::T*)weight, epsilon, hidden_size)
   if (keep) {
@@ -234,9 +238,11 @@ extern "C" int vla_fused_add_rms_norm(void* input, void* residual, const void* w
   if (!vec_ok(input, hidden_size, dtype) || !vec_ok(residual, hidden_size, dtype) ||
       !vec_ok(weight, hidden_size, dtype))
     return VLA_ERR_ARG;
-  const bool keep = hidden_size <= 2 * 256 * (dtype == VLA_F32 ? 4 : 8);
+  const int vecs = hidden_size / (dtype == VLA_F32 ? 4 : 8);
+  const int threads = vecs >= 1024 ? 1024 : ((vecs + 63) / 64) * 64;
+  const bool keep = vecs <= 2 * threads;
 #define VLA_RMS(KEEP_)                                                                          \
-  hipLaunchKernelGGL((rms_norm_kernel<S, true, KEEP_>), dim3(num_tokens), dim3(256), 0,          \
+  hipLaunchKernelGGL((rms_norm_kernel<S, true, KEEP_>), dim3(num_tokens), dim3(threads), 0,      \
                      (hipStream_t)stream, (typename S::T*)nullptr, (typename S::T*)input,        \
                      (typename S::T*)residual, (const typename S::T*)weight, epsilon, hidden_size)
   if (keep) {
