@@ -468,6 +468,8 @@ def main():
             except Exception:
                 pass
             stream = torch.cuda.Stream(device=device)
+        if world > 1:
+            graph = verify_ranks(graph, stream)
         with torch.cuda.stream(stream):
             if graph is None:
                 run = step
@@ -489,6 +491,73 @@ def main():
             barrier()
             elapsed = time.perf_counter() - t0
         return elapsed, graph, stream
+
+    verify = {"ranks_agree": None, "graph_matches_eager": None, "graph_eager_max_abs_diff": None}
+
+    def hidden_fingerprint():
+        """(64-bit position-weighted checksum of the final hidden state's bits, the state itself)."""
+        h = hidden_buf[0]
+        bits = h.contiguous().view(torch.int16).to(torch.int64).view(-1)
+        wts = torch.arange(bits.numel(), device=device, dtype=torch.int64) % 65521 + 1
+        return int((bits * wts).sum().item()), h.float().clone()
+
+    def all_ranks_equal(value: int) -> bool:
+        """Whether every rank holds the same 64-bit value (one all-gather over the Gloo group)."""
+        from vllm_legacy_amd.distributed import parallel_state as ps
+        mine = torch.tensor([value], dtype=torch.int64)
+        got = [torch.empty_like(mine) for _ in range(world)]
+        torch.distributed.all_gather(got, mine, group=ps.get_tensor_model_parallel_cpu_group())
+        return all(int(g.item()) == int(got[0].item()) for g in got)
+
+    def verify_ranks(graph, stream):
+        """Tensor-parallel runs, before anything is timed: one eager step and one graph replay from
+        the same inputs (the step rewrites the same cache slots with the same values, so it can
+        be repeated).  After the layer stack's last all-reduce and the final norm every rank must
+        hold the same hidden state bit for bit -- eagerly, and again from the graph -- and the
+        replayed step must reproduce the eager one: identical sampled tokens, hidden state equal
+        (the same collective on the same ranks) or within fp16 accumulation noise when the captured
+        all-reduce is another communicator's.  A graph whose collectives did not run would differ
+        grossly.  Ranks that disagree end the run; a graph that does not reproduce the eager step
+        is dropped and the steps are timed eagerly, with the reason in the result line."""
+        with torch.cuda.stream(stream):
+            step()
+            torch.cuda.synchronize()
+            sum_e, hid_e = hidden_fingerprint()
+            ids_e = next_ids.clone()
+            agree = all_ranks_equal(sum_e)
+            if graph is not None:
+                next_ids.fill_(-1)
+                graph.replay()
+                logits_part()
+                torch.cuda.synchronize()
+                sum_g, hid_g = hidden_fingerprint()
+                agree = all_ranks_equal(sum_g) and agree
+                diff = float((hid_g - hid_e).abs().max().item())
+                scale_ = float(hid_e.abs().max().item())
+                same_ids = bool(torch.equal(ids_e, next_ids)) if rank == 0 else True
+                ok = same_ids and (sum_g == sum_e or diff <= 2e-2 * max(scale_, 1e-6))
+                flag = torch.tensor([1 if ok else 0], dtype=torch.int32)
+                from vllm_legacy_amd.distributed import parallel_state as ps
+                torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN,
+                                             group=ps.get_tensor_model_parallel_cpu_group())
+                verify["graph_matches_eager"] = bool(flag.item())
+                verify["graph_eager_bit_identical"] = sum_g == sum_e
+                verify["graph_eager_max_abs_diff"] = diff
+                if not verify["graph_matches_eager"]:
+                    graph_note["reason"] = ("the graph replay did not reproduce the eager step "
+                                            f"(sampled tokens equal: {same_ids}, max |hidden diff| {diff:.3e} "
+                                            f"on a scale of {scale_:.3e})")
+                    if rank == 0:
+                        print(f"[bench] {graph_note['reason']}; timing eager steps instead", file=sys.stderr)
+                    graph = None
+            verify["ranks_agree"] = agree
+            if not agree:
+                if rank == 0:
+                    print("[bench] the ranks hold different hidden states after the same step: the "
+                          "tensor-parallel all-reduce is broken on this node", file=sys.stderr)
+                torch.distributed.barrier()
+                sys.exit(3)
+        return graph
 
     elapsed, graph, stream = measure()
     if ar_rec is not None and ar_rec["impl"] == "xgmi":
@@ -663,13 +732,19 @@ def main():
             gemm["rocprof_source"] = krec.get("source")
 
     # HBM bytes per launch from the committed PMC passes, when they were taken on this workload
-    traffic = None
+    traffic = traffic_src = None
+    attn_kernel = ops.paged_attention_kernel_name(B, hkv, d, BS, S, model.dtype, kvd)
     rec = load_profile_record("attn_traffic.json")
     try:
         w = rec["workload"]
+        # only a record taken on this workload AND on the kernel instantiation this run launches
         if (w["batch"], w["seq"], w["kv"], w["num_heads"], w["num_kv_heads"], w["head_size"],
-                w["block_size"]) == (B, S, args.kv, hq, hkv, d, BS):
+                w["block_size"]) == (B, S, args.kv, hq, hkv, d, BS) and rec["kernel"] == attn_kernel:
             traffic = rec["fetch_bytes"] + rec["write_bytes"]
+            traffic_src = rec.get("command")
+        elif rank == 0:
+            print(f"[bench] profiles/attn_traffic.json is for {rec.get('kernel')!r} on {w}; this run "
+                  f"launches {attn_kernel!r}: roofline.traffic left null", file=sys.stderr)
     except (TypeError, KeyError, ValueError):
         pass
     # the same kernel's average duration in the committed rocprofv3 kernel trace of this command
@@ -679,6 +754,18 @@ def main():
     if world == 1 and krec is not None and krec.get("workload") == {
             "batch": B, "seq": S, "kv": args.kv, "model": args.model, "quant": args.quant}:
         rocprof_attn_us, rocprof_src = krec.get("paged_attention_us"), krec.get("source")
+
+    # ---- the whole step against its HBM floor: every cached K/V byte once per KV head, every
+    # weight byte once (int4 words, zeros, scales; the 16-bit lm_head), per rank
+    step_bytes = algo_bytes * len(caches)
+    for lyr in model.layers:
+        for prm in lyr.parameters():
+            step_bytes += prm.numel() * prm.element_size()
+        for bname, buf in lyr.named_buffers():
+            step_bytes += buf.numel() * buf.element_size()
+    step_bytes += model.lm_head.numel() * model.lm_head.element_size()
+    step_bytes += B * cfg.hidden_size * model.embed_tokens.element_size()
+    step_floor_ms = step_bytes / (HBM_PEAK_GBS * 1e9) * 1e3
 
     if rank == 0:
         result = {
@@ -707,13 +794,17 @@ def main():
                 "graph": graph is not None,
                 "graph_fallback_reason": None if graph is not None else graph_note["reason"],
                 "ranks_seen": ranks_seen,
+                "ranks_agree": verify["ranks_agree"],
+                "graph_matches_eager": verify["graph_matches_eager"],
+                "graph_eager_bit_identical": verify.get("graph_eager_bit_identical"),
+                "graph_eager_max_abs_diff": verify["graph_eager_max_abs_diff"],
                 "all_reduce_impl": all_reduce_impl,
                 "all_reduce": ar_rec,
                 "global_batch": B,
                 "seq_len": S,
             },
             "roofline": {
-                "kernel": "paged_attention_v1 (pa_mfma_kernel)",
+                "kernel": f"paged_attention_v1: {attn_kernel}",
                 "bound": "hbm",
                 "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBS,
@@ -724,6 +815,7 @@ def main():
                 "frac_of_measured_read": round(achieved / HBM_MEASURED_READ_GBS, 4),
                 "frac_source": "launch_ms: HIP events around each launch on its stream, this run",
                 "traffic": traffic,
+                "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": algo_bytes,
                 "launch_ms": round(attn_ms, 4),
                 # rocprofv3 --kernel-trace --stats of this command on the committed build
@@ -734,6 +826,14 @@ def main():
                 "rocprof_source": rocprof_src,
                 "attention_share_of_step": round(attn_ms * len(caches) / ms_per_step, 3),
             },
+        }
+        result["roofline_step"] = {
+            "what": "whole decode step of one rank against the time its algorithmic HBM bytes take at peak",
+            "bound": "hbm", "bytes": step_bytes, "unit": "GB/s", "peak": HBM_PEAK_GBS,
+            "achieved": round(step_bytes / (ms_per_step * 1e-3) / 1e9, 1),
+            "frac": round(step_floor_ms / ms_per_step, 4),
+            "floor_ms": round(step_floor_ms, 3),
+            "bytes_kv": algo_bytes * len(caches), "bytes_weights": step_bytes - algo_bytes * len(caches),
         }
         if gemm is not None:
             result["roofline_gemm"] = gemm

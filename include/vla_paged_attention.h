@@ -43,6 +43,8 @@ extern "C" {
 #define VLA_ERR_HIP 7          /* a HIP runtime call failed (see vla_last_hip_error) */
 #define VLA_ERR_QUANT_SHAPE 8  /* AWQ/GPTQ shape constraint, gemm_kernels.cu:515-522 */
 #define VLA_ERR_SCRATCH 9      /* vla_paged_attention_v2_noalloc: problem exceeds its scratch */
+#define VLA_ERR_NOT_PREPARED 10 /* vla_paged_attention_v2_noalloc: first call on a device came
+                                   under stream capture without ..._noalloc_prepare() before it */
 
 #define VLA_PARTITION_SIZE 512 /* attention_kernels.cu:846, vllm/attention/ops/paged_attn.py:10 */
 
@@ -50,14 +52,24 @@ const char* vla_status_string(int status);
 int vla_last_hip_error(void);            /* hipError_t of the last VLA_ERR_HIP on this thread */
 int vla_abi_version(void);
 /* Test hook, no counterpart in the reference: 0 = choose the attention kernel per shape
- * (default), 1 = always run the generic kernel. Process-wide. */
+ * (default), 1 = always run the generic kernel.  Process-wide (all threads, all devices), kept in
+ * a relaxed atomic: a launch racing with the setter sees the old or the new value. */
 int vla_set_attention_path(int mode);
 /* No counterpart in the reference.  Cache policy of the K / V loads of the MFMA attention
  * kernel: 0 = by size (default: nontemporal loads when the launch reads more than the 256 MiB the
  * Infinity Cache holds, num_seqs x max_seq_len tokens of K and V), 1 = always nontemporal, 2 =
- * never.  Results do not depend on it.  Process-wide; the environment variable
- * VLA_KV_LOAD_POLICY sets the initial value. */
+ * never.  Results do not depend on it.  Process-wide (all threads, all devices), kept in a
+ * relaxed atomic; the environment variable VLA_KV_LOAD_POLICY sets the initial value. */
 int vla_set_kv_load_policy(int mode);
+/* No counterpart in the reference; for measurement tooling.  Writes into buf the name of the
+ * kernel instantiation a paged-attention call of this shape launches, spelled as a profiler's
+ * kernel trace prints it (e.g. "pa_mfma_kernel<vla::F16, true, 128, 16, false, true>": model
+ * dtype, fp8 cache, head size, block size, partitioned, nontemporal K/V loads; or
+ * "pa_generic_kernel"), so that a stored profile can be matched to the kernel a run launches.
+ * Assumes 16-byte aligned cache pointers and strides.  partitioned: 0 = V1, 1 = V2. */
+int vla_paged_attention_kernel_name(char* buf, int buf_len, int num_seqs, int num_kv_heads,
+                                    int head_size, int block_size, int max_seq_len, int dtype,
+                                    int kv_dtype, int partitioned);
 /* "auto" -> VLA_KV_AUTO, "fp8" / "fp8_e4m3" -> VLA_KV_FP8_E4M3, anything else -> -1
  * (DISPATCH_BY_KV_CACHE_DTYPE, csrc/quantization/fp8/amd/quant_utils.cuh:545-571). */
 int vla_kv_dtype_from_string(const char* name);
@@ -138,7 +150,11 @@ int vla_paged_attention_v2_ordered(void* out, float* exp_sums, float* max_logits
  *   512); larger problems return VLA_ERR_SCRATCH and launch nothing.
  *   All calls on one GPU share that GPU's array: calls that overlap in time on one GPU (two
  *   streams, two threads) race; calls on one stream, or ordered by events, are safe.  The first
- *   call on a device looks up the array's address on that device (no allocation). */
+ *   call on a device looks up the array's address on that device (no allocation; a HIP API call).
+ *   That lookup must not happen inside a stream capture: call
+ *   vla_paged_attention_v2_noalloc_prepare() once per device (with that device current) before
+ *   capturing, or make one eager call first; a first call that arrives under capture returns
+ *   VLA_ERR_NOT_PREPARED and launches nothing. */
 #define VLA_PA_V2_SCRATCH_BYTES (32 << 20)
 int vla_paged_attention_v2_noalloc(void* out, const void* query, const void* key_cache,
                                    const void* value_cache, int num_seqs, int num_heads,
@@ -151,6 +167,8 @@ int vla_paged_attention_v2_noalloc(void* out, const void* query, const void* key
                                    int blocksparse_local_blocks, int blocksparse_vert_stride,
                                    int blocksparse_block_size, int blocksparse_head_sliding_step,
                                    void* stream);
+/* Looks up the scratch array's address on the current device (idempotent, no allocation). */
+int vla_paged_attention_v2_noalloc_prepare(void);
 
 /* Replaces reshape_and_cache (csrc/cache.h:15-25; csrc/cache_kernels.cu:251-287).
  *   key, value [num_tokens, num_heads, head_size] model dtype, token strides in elements;

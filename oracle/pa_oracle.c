@@ -13,9 +13,14 @@
  * compiled from the reference tree (oracle/build_ref.py -> oracle/_ref/) and the
  * fixtures generated from them under tests/golden/: paged attention (f32, bf16),
  * reshape_and_cache, copy_blocks, RMSNorm / rotary / SiLU-and-mul, the FNUZ codec.
+ * The GPTQ functions (dequantise, exllama shuffle, act-order) are pinned against the
+ * reference's own Python packer (quantize_weights / gptq_pack / sort_weights of
+ * vllm/model_executor/layers/quantization/utils/quant_utils.py:39-146) through the
+ * fixtures tests/golden/gptq_*.npz made by tests/golden/make_golden_quant.py.
  * Parity unpinned (no reference fixture, no reference CPU implementation): fp16 and
- * fp8-KV attention, the block-sparse mask, swap_blocks, the AWQ/GPTQ functions, and
- * prompt attention with or without a cached prefix (checked against a float64
+ * fp8-KV attention, the block-sparse mask, swap_blocks, the AWQ functions (the
+ * reference's AWQ kernels are CUDA/PTX only and it holds no packer for the format),
+ * and prompt attention with or without a cached prefix (checked against a float64
  * evaluation of the definition the reference's tests use instead).
  *
  * dtype codes: 0 = float16, 1 = bfloat16, 2 = float32.

@@ -129,6 +129,24 @@ def _head_sharding_matches_full_attention(rank, world):
     assert np.array_equal(got.numpy(), full)
 
 
+def _rccl_one_rank_cannot_load(rank, world):
+    """The communicator's constructor is collective: when one rank cannot load the library, every
+    rank must come back unavailable (none may wait in the unique-id broadcast for the others)."""
+    from vllm_legacy_amd.distributed import parallel_state as ps
+    from vllm_legacy_amd.distributed.rccl_communicator import RcclCommunicator
+    c = RcclCommunicator(ps.get_tensor_model_parallel_cpu_group(), torch.device("cpu"),
+                         library_path="/nonexistent/librccl.so" if rank == 1 else None)
+    assert not c.available and c.disabled and c.reason
+    if rank == 1:
+        assert "OSError" in c.reason
+    assert RcclCommunicator.supports(torch.float16) and not RcclCommunicator.supports(torch.complex64)
+    c.close()
+
+
+def test_rccl_communicator_agrees_when_one_rank_cannot_load():
+    _run("_rccl_one_rank_cannot_load")
+
+
 def test_collectives_two_ranks():
     _run("_collectives")
 

@@ -3,8 +3,9 @@ in a static device array inside the library, for callers that cannot allocate.
 
 Checked through the C-ABI against vla_paged_attention_v2 (caller-owned scratch) bit for bit, on two
 calls in a row, the second with a smaller input (so stale contents of the shared array from the
-first call are in place when the second runs), with poisoned scratch in between, and for the size
-limit's error.
+first call are in place when the second runs), with the scratch poisoned in between (a call whose
+query is all NaN leaves NaN in every partial output, sum and maximum it writes), for a first call
+that arrives under stream capture in a fresh process, and for the size limit's error.
 """
 import numpy as np
 import pytest
@@ -56,6 +57,14 @@ def test_noalloc_equals_v2_on_two_calls_second_smaller(ops, kv_fp8):
     # once more in the other order: small, then big
     assert torch.equal(_v2_noalloc(ops, small).view(torch.int16), want_small.view(torch.int16))
     assert torch.equal(_v2_noalloc(ops, big).view(torch.int16), want_big.view(torch.int16))
+    # poison the shared array: the big problem with a NaN query fills every partial output, sum
+    # and maximum of its (larger) footprint with NaN; the next calls must not see any of it
+    q_keep = big.t_q.clone()
+    big.t_q.fill_(float("nan"))
+    assert torch.isnan(_v2_noalloc(ops, big)).all()
+    big.t_q.copy_(q_keep)
+    assert torch.equal(_v2_noalloc(ops, small).view(torch.int16), want_small.view(torch.int16))
+    assert torch.equal(_v2_noalloc(ops, big).view(torch.int16), want_big.view(torch.int16))
 
 
 def test_noalloc_other_dtypes_and_generic_kernel(ops):
@@ -103,3 +112,61 @@ def test_noalloc_rejects_problems_beyond_its_scratch(ops):
                                        1.0)
     torch.cuda.synchronize()
     assert (out == 7.0).all()      # nothing was launched
+
+
+_FRESH = r"""
+import sys, torch
+sys.path.insert(0, sys.argv[1])
+from oracle import oracle as O
+from tests import pa_testlib as T
+from vllm_legacy_amd import _custom_ops as ops
+c = T.make_attention_case(45, 4, (32, 8), 128, 16, O.DT_F16, True, False, max_seq_len=1500, num_blocks=256)
+want = T.run_hip_attention(ops, c, "v2")
+out = torch.zeros_like(c.t_q)
+def call():
+    ops.paged_attention_v2_noalloc(out, c.t_q, c.t_kc, c.t_vc, c.hkv, c.scale, c.t_bt, c.t_sl, c.bs,
+                                   c.max_seq_len, c.t_alibi, "fp8", 1.0)
+mode = sys.argv[2]
+if mode == "prepared":
+    ops.paged_attention_v2_noalloc_prepare()
+s = torch.cuda.Stream()
+g = torch.cuda.CUDAGraph()
+refused = False
+with torch.cuda.stream(s):
+    try:
+        with torch.cuda.graph(g, stream=s):
+            call()                  # the first call of this process on this device
+    except RuntimeError as e:
+        refused = "prepare" in str(e)
+        if not refused:
+            raise
+torch.cuda.synchronize()
+if mode == "prepared":
+    assert not refused
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out.view(torch.int16), want.view(torch.int16))
+else:
+    assert refused, "an unprepared first call under capture must be refused"
+    # the refusal launched nothing and left the library usable
+    with torch.cuda.stream(torch.cuda.Stream()):
+        call()
+    torch.cuda.synchronize()
+    assert torch.equal(out.view(torch.int16), want.view(torch.int16))
+print("OK")
+"""
+
+
+@pytest.mark.parametrize("mode", ["prepared", "unprepared"])
+def test_first_call_of_a_process_under_capture(mode):
+    """A fresh process whose first noalloc call comes from inside a stream capture: after
+    paged_attention_v2_noalloc_prepare() the captured call replays V2's bits; without it the call
+    is refused with a message naming the prepare call (the address lookup is a HIP API call that
+    must stay out of a capture) and nothing is launched."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", _FRESH, root, mode], capture_output=True, text=True,
+                       timeout=150)
+    assert r.returncode == 0 and "OK" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])

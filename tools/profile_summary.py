@@ -4,6 +4,8 @@
   python tools/profile_summary.py pmc    <..._counter_collection.csv>  <out.csv>
   python tools/profile_summary.py record <..._kernel_stats.csv> <out.json> <source note> \
                                          [batch seq kv model quant]
+  python tools/profile_summary.py attn_traffic <fetch pmc summary> <write pmc summary> <out.json> <note>
+  python tools/profile_summary.py gemm_traffic <fetch pmc summary> <write pmc summary> <out.json> <note>
 
 `record` writes the small JSON that bench.py reads for `roofline.rocprof_avg_us`: the average
 duration of the paged-attention kernel and the summed averages of one layer's four int4 GEMM
@@ -125,7 +127,46 @@ def gemm_traffic(fetch_csv, write_csv, dst, note):
         fh.write("\n")
 
 
+def attn_traffic(fetch_csv, write_csv, dst, note, workload):
+    """HBM bytes of one paged-attention launch from two PMC summaries (this tool's `pmc` output for
+    FETCH_SIZE and for WRITE_SIZE of `tools/attn_bench.py` on the benchmark's shape).  The record
+    names the kernel instantiation the counters were taken on; bench.py uses the record only when
+    that name is the one its own launch runs."""
+    import json
+
+    def row(path, counter):
+        best = None
+        for r in csv.DictReader(open(path)):
+            if r["Counter"].startswith(counter) and "pa_mfma_kernel" in r["Kernel"]:
+                if best is None or int(r["Dispatches"]) > int(best["Dispatches"]):
+                    best = r
+        if best is None:
+            raise SystemExit(f"no pa_mfma_kernel row with {counter} in {path}")
+        return best
+
+    f, w = row(fetch_csv, "FETCH_SIZE"), row(write_csv, "WRITE_SIZE")
+    m = re.search(r"pa_mfma_kernel<[^>]*>", f["Kernel"])
+    if m is None or m.group(0) not in w["Kernel"]:
+        raise SystemExit("the two passes did not run the same kernel instantiation")
+    rec = {"comment": "HBM bytes per paged_attention_v1 launch from rocprofv3 PMC passes (one counter "
+                      "per pass), read by bench.py for roofline.traffic when workload and kernel match. "
+                      "FETCH_SIZE/WRITE_SIZE are KiB; FETCH_SIZE is doubled (gfx950 counts 64-byte "
+                      "requests as 32).",
+           "command": note, "workload": workload, "kernel": m.group(0),
+           "dispatches": int(f["Dispatches"]),
+           "fetch_size_kib_avg": float(f["AvgValue"]), "write_size_kib_avg": float(w["AvgValue"]),
+           "fetch_bytes": int(f["AvgBytes(corrected)"]), "write_bytes": int(w["AvgBytes(corrected)"])}
+    with open(dst, "w") as fh:
+        json.dump(rec, fh, indent=1)
+        fh.write("\n")
+
+
 if __name__ == "__main__":
+    if sys.argv[1] == "attn_traffic":
+        attn_traffic(sys.argv[2], sys.argv[3], sys.argv[4], sys.argv[5],
+                     {"batch": 256, "seq": 4096, "kv": "fp8", "num_heads": 32, "num_kv_heads": 8,
+                      "head_size": 128, "block_size": 16})
+        sys.exit(0)
     if sys.argv[1] == "gemm_traffic":
         gemm_traffic(*sys.argv[2:6])
         sys.exit(0)

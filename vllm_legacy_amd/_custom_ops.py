@@ -257,6 +257,26 @@ def paged_attention_v2_noalloc(out: torch.Tensor, query: torch.Tensor, key_cache
             blocksparse_head_sliding_step, _stream(query.device)), "paged_attention_v2_noalloc")
 
 
+def paged_attention_v2_noalloc_prepare(device=None) -> None:
+    """Look up the static scratch of paged_attention_v2_noalloc on `device` (default: the current
+    one).  Needed once per device before the op's first call may come from inside a graph capture:
+    the lookup is a HIP API call, which a capture may not contain."""
+    with torch.cuda.device(device):
+        check(_lib.lib().vla_paged_attention_v2_noalloc_prepare(), "paged_attention_v2_noalloc_prepare")
+
+
+def paged_attention_kernel_name(num_seqs: int, num_kv_heads: int, head_size: int, block_size: int,
+                                max_seq_len: int, dtype: torch.dtype, kv_cache_dtype: str,
+                                partitioned: bool = False) -> str:
+    """Name of the kernel instantiation a paged-attention call of this shape launches, as a
+    profiler's kernel trace spells it (measurement tooling; not in the reference)."""
+    buf = C.create_string_buffer(160)
+    check(_lib.lib().vla_paged_attention_kernel_name(
+        buf, len(buf), num_seqs, num_kv_heads, head_size, block_size, max_seq_len, _DTYPE[dtype],
+        _lib.kv_dtype_code(kv_cache_dtype), 1 if partitioned else 0))
+    return buf.value.decode()
+
+
 def prefill_attention(out: torch.Tensor, query: torch.Tensor, key: torch.Tensor,
                       value: torch.Tensor, cu_seqlens: torch.Tensor, max_seqlen: int,
                       scale: float, alibi_slopes: Optional[torch.Tensor] = None) -> None:

@@ -26,7 +26,8 @@ EXPORTS = [
     "vla_set_kv_load_policy",
     "vla_kv_dtype_from_string", "vla_paged_attention_v1", "vla_paged_attention_v2",
     "vla_paged_attention_v1_ordered", "vla_paged_attention_v2_ordered",
-    "vla_paged_attention_v2_noalloc",
+    "vla_paged_attention_v2_noalloc", "vla_paged_attention_v2_noalloc_prepare",
+    "vla_paged_attention_kernel_name",
     "vla_reshape_and_cache", "vla_copy_blocks", "vla_swap_blocks", "vla_convert_fp8",
     "vla_awq_dequantize", "vla_awq_gemm", "vla_gptq_dequantize", "vla_gptq_gemm",
     "vla_gptq_shuffle", "vla_get_max_shared_memory_per_block", "vla_awq_repack",
@@ -122,6 +123,8 @@ def lib():
                                                      i, i, p, i64, i64, i64, i, i, f, i, i, i, i,
                                                      i, p, p]
         L.vla_paged_attention_v2_noalloc.argtypes = L.vla_paged_attention_v1.argtypes
+        L.vla_paged_attention_v2_noalloc_prepare.argtypes = []
+        L.vla_paged_attention_kernel_name.argtypes = [C.c_char_p, i, i, i, i, i, i, i, i, i]
         L.vla_reshape_and_cache.argtypes = [p, p, p, p, p, i, i, i, i, i, i64, i64, i, i, f, p]
         L.vla_copy_blocks.argtypes = [p, p, i, p, i, i64, p]
         L.vla_swap_blocks.argtypes = [p, p, p, i, i64, i, p]

@@ -2,14 +2,18 @@
 // status strings, argument validation and dispatch for the two attention ops.
 #include "vla_common.h"
 
+#include <stdio.h>
 #include <string.h>
 
+#include <atomic>
 #include <mutex>
 
 namespace vla {
 static thread_local int g_last_hip_error = 0;
 void set_last_hip_error(int e) { g_last_hip_error = e; }
-static int g_attention_path = 0;  // 0 = pick per shape, 1 = always the generic kernel
+// Process-wide knobs, written by their setters and read by every launch on any thread: relaxed
+// atomics (a launch sees either the old or the new value, never a torn one).
+static std::atomic<int> g_attention_path{0};  // 0 = pick per shape, 1 = always the generic kernel
 }  // namespace vla
 
 using namespace vla;
@@ -29,6 +33,9 @@ extern "C" const char* vla_status_string(int status) {
       return "Problem too large for the static scratch of vla_paged_attention_v2_noalloc "
              "(num_seqs * num_heads * partitions * (head_size * element size + 8) bytes must fit "
              "VLA_PA_V2_SCRATCH_BYTES)";
+    case VLA_ERR_NOT_PREPARED:
+      return "vla_paged_attention_v2_noalloc: first call on this device is inside a stream capture; "
+             "call vla_paged_attention_v2_noalloc_prepare() on the device before capturing";
     default: return "unknown status";
   }
 }
@@ -36,29 +43,54 @@ extern "C" const char* vla_status_string(int status) {
 extern "C" int vla_last_hip_error(void) { return g_last_hip_error; }
 extern "C" int vla_set_attention_path(int mode) {
   if (mode != 0 && mode != 1) return VLA_ERR_ARG;
-  g_attention_path = mode;
+  g_attention_path.store(mode, std::memory_order_relaxed);
   return VLA_OK;
 }
 // K / V load policy of the MFMA attention kernel: 0 by size (nontemporal when the launch reads
 // more than the 256 MiB of Infinity Cache can hold, i.e. when nothing it reads will be read again
 // from cache), 1 always nontemporal, 2 never.
-static int g_kv_load_policy = [] {
+static std::atomic<int> g_kv_load_policy{[] {
   const char* e = getenv("VLA_KV_LOAD_POLICY");
   const int v = e ? atoi(e) : 0;
   return v >= 0 && v <= 2 ? v : 0;
-}();
+}()};
 extern "C" int vla_set_kv_load_policy(int mode) {
   if (mode < 0 || mode > 2) return VLA_ERR_ARG;
-  g_kv_load_policy = mode;
+  g_kv_load_policy.store(mode, std::memory_order_relaxed);
   return VLA_OK;
 }
 static int kv_nontemporal(int num_seqs, int max_tokens, int num_kv_heads, int head_size, int kv_dtype) {
-  if (g_kv_load_policy != 0) return g_kv_load_policy == 1;
+  const int policy = g_kv_load_policy.load(std::memory_order_relaxed);
+  if (policy != 0) return policy == 1;
   const int64_t bytes = (int64_t)num_seqs * max_tokens * num_kv_heads * head_size * 2 *
                         (kv_dtype == VLA_KV_FP8_E4M3 ? 1 : 2);
   return bytes > (256ll << 20);
 }
 extern "C" int vla_abi_version(void) { return 1; }
+
+// Which kernel a paged-attention call of this shape runs on, spelled the way a profiler prints the
+// instantiation ("pa_mfma_kernel<vla::F16, true, 128, 16, false, true>": model dtype, fp8 cache,
+// head size, block size, partitioned (V2), nontemporal K/V loads), or "pa_generic_kernel" for
+// shapes the MFMA kernel does not take.  Assumes 16-byte aligned caches and strides.
+extern "C" int vla_paged_attention_kernel_name(char* buf, int buf_len, int num_seqs, int num_kv_heads,
+                                               int head_size, int block_size, int max_seq_len,
+                                               int dtype, int kv_dtype, int partitioned) {
+  if (!buf || buf_len <= 0) return VLA_ERR_ARG;
+  const bool mfma_shape =
+      g_attention_path.load(std::memory_order_relaxed) == 0 && (dtype == VLA_F16 || dtype == VLA_BF16) &&
+      (block_size == 8 || block_size == 16 || block_size == 32) &&
+      (head_size == 64 || head_size == 80 || head_size == 96 || head_size == 112 ||
+       head_size == 128 || head_size == 192 || head_size == 256);
+  if (!mfma_shape) {
+    snprintf(buf, buf_len, "pa_generic_kernel");
+    return VLA_OK;
+  }
+  const int nt = kv_nontemporal(num_seqs, max_seq_len, num_kv_heads, head_size, kv_dtype);
+  snprintf(buf, buf_len, "pa_mfma_kernel<vla::%s, %s, %d, %d, %s, %s>", dtype == VLA_F16 ? "F16" : "BF16",
+           kv_dtype == VLA_KV_FP8_E4M3 ? "true" : "false", head_size, block_size,
+           partitioned ? "true" : "false", nt ? "true" : "false");
+  return VLA_OK;
+}
 
 extern "C" int vla_kv_dtype_from_string(const char* name) {
   if (!name) return -1;
@@ -123,7 +155,7 @@ extern "C" int vla_paged_attention_v1_ordered(
   hipStream_t s = (hipStream_t)stream;
   // the block-sparse variant (vert_stride > 1, ref attention_kernels.cu:821) runs on the generic
   // kernel only
-  const bool generic_only = g_attention_path == 1 || blocksparse_vert_stride > 1;
+  const bool generic_only = g_attention_path.load(std::memory_order_relaxed) == 1 || blocksparse_vert_stride > 1;
   rc = generic_only ? -1 : launch_paged_attention_mfma(p, dtype, kv_dtype, s);
   if (rc >= 0) return rc;
   return launch_paged_attention_generic(p, dtype, kv_dtype, s);
@@ -178,7 +210,7 @@ extern "C" int vla_paged_attention_v2_ordered(
   p.seq_order = seq_order;
   p.kv_nontemporal = kv_nontemporal(num_seqs, max_seq_len, num_kv_heads, head_size, kv_dtype);
   hipStream_t s = (hipStream_t)stream;
-  const bool generic_only = g_attention_path == 1 || blocksparse_vert_stride > 1;
+  const bool generic_only = g_attention_path.load(std::memory_order_relaxed) == 1 || blocksparse_vert_stride > 1;
   rc = generic_only ? -1 : launch_paged_attention_mfma(p, dtype, kv_dtype, s);
   if (rc < 0) rc = launch_paged_attention_generic(p, dtype, kv_dtype, s);
   if (rc != VLA_OK) return rc;
@@ -215,13 +247,20 @@ constexpr int kMaxDevices = 64;
 std::mutex g_scratch_mutex;
 void* g_scratch_ptr[kMaxDevices] = {};
 
-// device pointer of `scratch` on the current device, or nullptr (+ last HIP error) on failure
-int scratch_for_current_device(unsigned char** out) {
+// Device pointer of `scratch` on the current device.  The first call on a device looks the
+// address up (a HIP API call that may load the code object): that must not happen while `stream`
+// is being captured into a graph, so an unprepared device under capture is an error, not a lookup.
+int scratch_for_current_device(unsigned char** out, hipStream_t stream = nullptr, bool check_capture = false) {
   int dev = -1;
   VLA_HIP_CHECK(hipGetDevice(&dev));
   if (dev < 0 || dev >= kMaxDevices) return VLA_ERR_ARG;
   std::lock_guard<std::mutex> lock(g_scratch_mutex);
   if (!g_scratch_ptr[dev]) {
+    if (check_capture) {
+      hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+      VLA_HIP_CHECK(hipStreamIsCapturing(stream, &st));
+      if (st != hipStreamCaptureStatusNone) return VLA_ERR_NOT_PREPARED;
+    }
     void* ptr = nullptr;
     VLA_HIP_CHECK(hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)));
     if (!ptr) return VLA_ERR_HIP;
@@ -233,6 +272,12 @@ int scratch_for_current_device(unsigned char** out) {
 
 inline int64_t round_up_256(int64_t v) { return (v + 255) / 256 * 256; }
 }  // namespace
+
+extern "C" int vla_paged_attention_v2_noalloc_prepare(void) {
+  (void)hipGetLastError();
+  unsigned char* base = nullptr;
+  return scratch_for_current_device(&base);
+}
 
 extern "C" int vla_paged_attention_v2_noalloc(
     void* out, const void* query, const void* key_cache, const void* value_cache, int num_seqs,
@@ -252,7 +297,7 @@ extern "C" int vla_paged_attention_v2_noalloc(
   const int64_t stat_bytes = round_up_256(rows * 4);
   if (tmp_bytes + 2 * stat_bytes > (int64_t)VLA_PA_V2_SCRATCH_BYTES) return VLA_ERR_SCRATCH;
   unsigned char* base = nullptr;
-  int rc = scratch_for_current_device(&base);
+  int rc = scratch_for_current_device(&base, (hipStream_t)stream, true);
   if (rc != VLA_OK) return rc;
   // Nothing in the scratch has to start at zero: the reduce reads, per sequence, exactly the
   // partitions below ceil(seq_len / 512), and the partition pass of the same call has written

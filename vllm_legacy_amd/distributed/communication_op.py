@@ -127,7 +127,8 @@ def tensor_model_parallel_all_reduce(input_, dtype: torch.dtype = torch.float16)
         # current stream through the ctypes communicator, as the reference does while capturing
         # (communication_op.py:85-100 with pynccl.py:109-127)
         rccl = get_tp_rccl_communicator()
-        if rccl is not None and (_RCCL_CTYPES_ALWAYS or torch.cuda.is_current_stream_capturing()):
+        if rccl is not None and rccl.supports(input_.dtype) and (
+                _RCCL_CTYPES_ALWAYS or torch.cuda.is_current_stream_capturing()):
             with rccl.change_state(True, torch.cuda.current_stream(input_.device)):
                 rccl.all_reduce(input_)
             return input_

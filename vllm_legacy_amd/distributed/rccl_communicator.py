@@ -96,15 +96,20 @@ class RcclCommunicator:
         if self.world_size == 1 and not allow_single_rank:
             self.reason = "single rank"
             return
+        uid = ncclUniqueId()
         try:
             self.rccl = RcclLibrary(library_path)
             self.version = self.rccl.version()
+            if self.rank == 0:
+                self.rccl.check(self.rccl.L.ncclGetUniqueId(C.byref(uid)), "ncclGetUniqueId")
         except Exception as e:  # noqa: BLE001  (missing file, missing symbol: stay unavailable)
             self.reason = f"{type(e).__name__}: {e}"
+        # The constructor is collective from here on (broadcast, ncclCommInitRank): whether it goes
+        # on must be one decision for the whole group, or the ranks that loaded the library would
+        # wait in the broadcast for the one that did not.
+        if not self._all_ranks(not self.reason):
+            self.reason = self.reason or "the RCCL library could not be loaded on another rank"
             return
-        uid = ncclUniqueId()
-        if self.rank == 0:
-            self.rccl.check(self.rccl.L.ncclGetUniqueId(C.byref(uid)), "ncclGetUniqueId")
         if self.world_size > 1:
             t = torch.tensor(list(uid.internal), dtype=torch.uint8)
             dist.broadcast(t, src=dist.get_process_group_ranks(group)[0], group=group)
@@ -114,8 +119,13 @@ class RcclCommunicator:
             device = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
         self.device = torch.device(device)
         with torch.cuda.device(self.device):
-            self.rccl.check(self.rccl.L.ncclCommInitRank(C.byref(self.comm), self.world_size, uid,
-                                                         self.rank), "ncclCommInitRank")
+            rc = self.rccl.L.ncclCommInitRank(C.byref(self.comm), self.world_size, uid, self.rank)
+            if not self._all_ranks(rc == ncclSuccess):
+                self.reason = ("ncclCommInitRank failed" + (
+                    f": {self.rccl.L.ncclGetErrorString(rc).decode()}" if rc != ncclSuccess
+                    else " on another rank"))
+                self.close()
+                return
             self.stream = torch.cuda.Stream()
             self.available = True
             self.disabled = False
@@ -126,6 +136,20 @@ class RcclCommunicator:
         # like the reference's, the communicator is switched on only where it is wanted
         # (change_state around a graph capture)
         self.disabled = True
+
+    def _all_ranks(self, flag: bool) -> bool:
+        """True when `flag` holds on every rank of the group (one Gloo all-reduce)."""
+        if self.group is None or self.world_size == 1:
+            return bool(flag)
+        t = torch.tensor([1 if flag else 0], dtype=torch.int32)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self.group)
+        return int(t.item()) == 1
+
+    @staticmethod
+    def supports(dtype: torch.dtype) -> bool:
+        """Whether all_reduce takes tensors of this dtype (callers fall back to torch.distributed
+        for the others instead of failing in the middle of a capture)."""
+        return dtype in _DTYPES
 
     def all_reduce(self, tensor: torch.Tensor, op=dist.ReduceOp.SUM, stream=None) -> None:
         """In place, on `stream` (default: the communicator's own stream)."""
@@ -154,7 +178,7 @@ class RcclCommunicator:
             self.disabled, self.stream = old
 
     def close(self) -> None:
-        if self.comm:
+        if self.comm and getattr(self, "rccl", None) is not None:
             self.rccl.L.ncclCommDestroy(self.comm)
             self.comm = C.c_void_p()
         self.available, self.disabled = False, True
