@@ -150,11 +150,83 @@ def fnuz_case():
     print("fnuz codec table done", x.size)
 
 
+def greedy_loop_case(ref, name, seed, prompt_len=37, steps=16):
+    """Configuration 1 as a loop: one sequence, OPT-125M's attention shape (12 heads of 64, bf16,
+    block 16), a prompt followed by `steps` greedy decode steps in which step t's cache write
+    feeds step t + 1's attention.  The attention side is the reference's CPU executor path
+    (vllm/attention/backends/torch_sdpa.py:159-228): every step writes its key / value with the
+    reference's reshape_and_cache (csrc/cpu/cache.cpp); the prompt runs torch's
+    scaled_dot_product_attention (is_causal, :199-206), each decode step the reference's
+    paged_attention_v1 (csrc/cpu/attention.cpp:421-438) over everything cached so far.  Around
+    it sits a one-layer stand-in for the model, just enough to close the greedy loop: token ->
+    embedding row -> q | k | v by one projection -> attention -> logits by one projection ->
+    argmax -> next token (bf16 tensors, torch matmuls on the CPU).  Stored per step: the token,
+    q / k / v as they went into the reference attention, its output, and the argmax."""
+    g = torch.Generator().manual_seed(seed)
+    dt = torch.bfloat16
+    heads, d, bs, hidden, vocab = 12, 64, 16, 768, 512
+    scale = float(d**-0.5)
+    x = 16 // 2
+    nb = 8
+    embed = (torch.randn(vocab, hidden, generator=g) * 1.0).to(dt)
+    w_qkv = (torch.randn(hidden, 3 * hidden, generator=g) * hidden**-0.5).to(dt)
+    w_out = (torch.randn(hidden, vocab, generator=g) * hidden**-0.5).to(dt)
+    prompt = torch.randint(0, vocab, (prompt_len, ), generator=g)
+    blocks = torch.randperm(nb, generator=g)[:(prompt_len + steps + bs - 1) // bs].to(torch.int32)
+    kc = torch.zeros(nb, heads, d // x, bs, x, dtype=dt)
+    vc = torch.zeros(nb, heads, d, bs, dtype=dt)
+    slot = lambda pos: int(blocks[pos // bs]) * bs + pos % bs          # noqa: E731
+
+    def qkv_of(tokens):
+        h = embed[tokens]
+        qkv = (h.float() @ w_qkv.float()).to(dt)
+        q, k, v = qkv.split(hidden, dim=-1)
+        return q.contiguous(), k.contiguous(), v.contiguous()
+
+    def next_token(out_row):
+        return int(torch.argmax(out_row.float() @ w_out.float()))
+
+    # prompt (torch_sdpa.py:159-208)
+    q, k, v = qkv_of(prompt)
+    slots = torch.tensor([slot(i) for i in range(prompt_len)], dtype=torch.int64)
+    ref.reshape_and_cache(k.view(-1, heads, d), v.view(-1, heads, d), kc, vc, slots, "auto", 1.0)
+    qh, kh, vh = (t.view(-1, heads, d).movedim(0, 1) for t in (q, k, v))
+    out = torch.nn.functional.scaled_dot_product_attention(qh, kh, vh, attn_mask=None, dropout_p=0.0,
+                                                           is_causal=True, scale=scale)
+    out = out.movedim(1, 0).reshape(prompt_len, hidden).contiguous()
+    rec = dict(prompt=prompt.numpy(), prompt_q=bits(q), prompt_k=bits(k), prompt_v=bits(v),
+               prompt_out=bits(out), prompt_slots=slots.numpy(), block_table=blocks.numpy(),
+               scale=scale, embed=bits(embed), w_qkv=bits(w_qkv), w_out=bits(w_out))
+    tok = next_token(out[-1])
+    toks, qs, ks, vs, outs = [], [], [], [], []
+    for t in range(steps):
+        pos = prompt_len + t
+        toks.append(tok)
+        q, k, v = qkv_of(torch.tensor([tok]))
+        ref.reshape_and_cache(k.view(1, heads, d), v.view(1, heads, d), kc, vc,
+                              torch.tensor([slot(pos)], dtype=torch.int64), "auto", 1.0)
+        o = torch.zeros(1, heads, d, dtype=dt)
+        ref.paged_attention_v1(o, q.view(1, heads, d), kc, vc, heads, scale, blocks.view(1, -1),
+                               torch.tensor([pos + 1], dtype=torch.int32), bs, pos + 1, None, "auto",
+                               1.0, 0, 0, 0, 64, 0)
+        qs.append(bits(q)); ks.append(bits(k)); vs.append(bits(v)); outs.append(bits(o.view(1, hidden)))
+        tok = next_token(o.view(hidden))
+    toks.append(tok)
+    rec.update(tokens=np.array(toks, dtype=np.int64), step_q=np.concatenate(qs), step_k=np.concatenate(ks),
+               step_v=np.concatenate(vs), step_out=np.concatenate(outs), key_cache_final=bits(kc),
+               value_cache_final=bits(vc))
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **rec)
+    print(name, "tokens", toks)
+
+
 def main():
     assert build_ref.build(), "reference tree not available"
     ref = build_ref.load_ref()
     assert ref is not None, "reference CPU kernels need AVX-512 on this host"
     torch.manual_seed(0)
+    greedy_loop_case(ref, "loop_bf16_opt125m", 21)
+    if "--loop-only" in sys.argv:
+        return
     # OPT-125M on the reference's CPU executor (12 heads of 64, one sequence, bf16, block 16:
     # vllm/attention/backends/torch_sdpa.py:216-228 -> csrc/cpu/attention.cpp:421-438) and the
     # per-rank head shape of Llama-3-70B under 8-way tensor parallelism (8 query heads, 1 KV head)

@@ -111,6 +111,22 @@ class QuantLinear(nn.Module):
             perm = torch.randperm(in_features, device=device, generator=generator)
             self.g_idx.data = (perm // group_size).to(torch.int32)
 
+    def load(self, tensors) -> None:
+        """Install one rank's checkpoint tensors (already stacked and sharded: qweight, qzeros,
+        scales and, for GPTQ, g_idx) and forget every first-use re-layout made from the old ones
+        (the AWQ repack, the exllama shuffle: awq.py / gptq.py do them again on the next forward)."""
+        from vllm_legacy_amd.quantization.gptq import ExllamaState
+        for name, t in tensors.items():
+            p = getattr(self, name)
+            if name != "g_idx" and tuple(t.shape) != tuple(p.shape):
+                raise ValueError(f"{name}: checkpoint shard {tuple(t.shape)} does not fit the "
+                                 f"layer's {tuple(p.shape)}")
+            p.data = t.to(device=p.device, dtype=p.dtype).contiguous()
+        if hasattr(self, "_k_packed"):
+            del self._k_packed
+        if self.quant == "gptq" and getattr(self, "exllama_state", None) == ExllamaState.READY:
+            self.exllama_state = ExllamaState.UNINITIALIZED
+
     def forward(self, x: torch.Tensor, defer_reduce: bool = False):
         """defer_reduce: the caller feeds the result to a kernel that can sum split-K slabs
         itself, so an ops.SplitKSlabs may come back instead of a tensor."""
@@ -264,6 +280,52 @@ class LlamaDecodeModel(nn.Module):
                                      self.rotary_emb)
         hidden, _ = self.norm(hidden, residual)
         return hidden
+
+    def load_weights(self, tensors, method: Optional[str] = None, desc_act: bool = False,
+                     group_size: int = 128) -> int:
+        """Fill the stack from checkpoint tensors under their Hugging Face names (a mapping
+        name -> tensor, e.g. read from safetensors): q/k/v and gate/up stacked into the merged
+        projections and every linear cut to this rank's shard as LlamaForCausalLM.load_weights
+        does through the parameters' weight loaders (vllm/model_executor/models/llama.py:411-469,
+        layers/linear.py:341-459, :527-660, :729-747); embedding and lm_head rows cut to this
+        rank's vocabulary shard (layers/vocab_parallel_embedding.py:90-140); a per-layer
+        `self_attn.kv_scale` lands on the attention layer (llama.py:448-460).  Returns the number
+        of tensors consumed."""
+        from vllm_legacy_amd.model_loader import load_llama_layer_weights
+        method = method or self.layers[0].qkv_proj.quant
+        n = 0
+        for i, layer in enumerate(self.layers):
+            per_linear = load_llama_layer_weights(
+                tensors, i, method, self.rank, self.tp, self.cfg.num_attention_heads,
+                self.cfg.num_key_value_heads, self.cfg.head_dim, desc_act, group_size)
+            for lname, got in per_linear.items():
+                getattr(layer, lname).load(got)
+                n += len(got)
+            for norm in ("input_layernorm", "post_attention_layernorm"):
+                key = f"model.layers.{i}.{norm}.weight"
+                if key in tensors:
+                    w = getattr(layer, norm).weight
+                    w.data = tensors[key].to(device=w.device, dtype=w.dtype).contiguous()
+                    n += 1
+            key = f"model.layers.{i}.self_attn.kv_scale"
+            if key in tensors:
+                layer.attn._kv_scale = float(tensors[key])
+                n += 1
+        lo, hi = self.rank * self.vocab_shard, (self.rank + 1) * self.vocab_shard
+        for key, param in (("model.embed_tokens.weight", self.embed_tokens),
+                           ("lm_head.weight", self.lm_head), ("model.norm.weight", self.norm.weight)):
+            if key in tensors:
+                t = tensors[key]
+                t = t if param is self.norm.weight else t[lo:hi]
+                param.data = t.to(device=param.device, dtype=param.dtype).contiguous()
+                n += 1
+        return n
+
+    def load_kv_cache_scales(self, quantization_param_path: str) -> int:
+        """Per-layer fp8 KV-cache scaling factors from a kv_cache_scales.json
+        (models/llama.py:474-493); returns how many layers received one."""
+        from vllm_legacy_amd.model_loader import load_kv_cache_scales
+        return load_kv_cache_scales(self.layers, quantization_param_path, self.rank, self.tp)
 
     def compute_logits(self, hidden: torch.Tensor) -> Optional[torch.Tensor]:
         """Column-parallel lm_head, gathered on rank 0 (layers/logits_processor.py:61-75)."""
