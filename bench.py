@@ -333,6 +333,14 @@ def main():
         faulthandler.dump_traceback_later(int(os.environ["VLA_BENCH_WATCHDOG"]), exit=True)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
+    stdout_fd = None
+    if world > 1:
+        # the result line must be the only thing on stdout: the Gloo library announces every
+        # group it connects on file descriptor 1, so until the line is printed that descriptor
+        # points at stderr
+        sys.stdout.flush()
+        stdout_fd = os.dup(1)
+        os.dup2(2, 1)
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     # VLA_BENCH_REHEARSAL=1: run the tensor-parallel code path with every rank on GPU 0 and Gloo
     # collectives (a one-GPU box cannot host an RCCL group); numbers from it mean nothing.
@@ -409,6 +417,11 @@ def main():
         logits = model.compute_logits(hidden_buf[0])
         if logits is not None:
             next_ids.copy_(torch.argmax(logits, dim=-1))
+        if world > 1:
+            # once per step, before the point where a serving loop reads the sampled tokens: the
+            # peer-memory all-reduce's 4-byte error read (a no-op on RCCL)
+            from vllm_legacy_amd.distributed import communication_op as _co
+            _co.tensor_model_parallel_poll_all_reduce_error(device)
 
     def step():
         forward_part()
@@ -561,15 +574,11 @@ def main():
 
     elapsed, graph, stream = measure()
     if ar_rec is not None and ar_rec["impl"] == "xgmi":
-        # a barrier wait that timed out during the run voids it: measure again on RCCL
-        from vllm_legacy_amd.distributed import parallel_state as ps
-        comm = ps.get_tp_xgmi_all_reduce(device)
-        bad = torch.tensor([comm.error_count()], dtype=torch.int32)
-        torch.distributed.all_reduce(bad, op=torch.distributed.ReduceOp.MAX,
-                                     group=ps.get_tensor_model_parallel_cpu_group())
-        if int(bad.item()) > 0:
-            ps.set_tp_xgmi_all_reduce(None)
-            comm.close()
+        # a barrier wait that timed out during the run voids it (the outputs since are NaN on every
+        # rank): the collective verdict on the counter every step polled; on failure the
+        # communicator is closed on all ranks and the steps are measured again on RCCL
+        from vllm_legacy_amd.distributed import communication_op as _co3
+        if not _co3.tensor_model_parallel_check_all_reduce(device):
             ar_rec.update(impl="rccl", note="barrier timeouts during the xgmi run; re-measured on RCCL")
             elapsed, graph, stream = measure()
     all_reduce_impl = "none"
@@ -845,7 +854,12 @@ def main():
             except Exception as e:
                 result["cpu_baseline"] = {"value": None, "unit": "tokens/s", "cores": 0,
                                           "kind": "port", "sample": f"failed: {e}"}
+        if stdout_fd is not None:
+            sys.stdout.flush()
+            os.dup2(stdout_fd, 1)
         print(json.dumps(result), flush=True)
+        if stdout_fd is not None:
+            os.dup2(2, 1)
     if world > 1:
         torch.distributed.barrier()
         from vllm_legacy_amd.distributed import parallel_state as ps

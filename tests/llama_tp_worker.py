@@ -32,14 +32,14 @@ def main():
         for lin in (layer.qkv_proj, layer.o_proj, layer.gate_up_proj, layer.down_proj):
             lin.scales.data = (lin.scales.data.float() * 0.1).half()
     # count how the all-reduce is fed
-    fed = {"slabs": 0, "tensors": 0, "norm": 0}
+    fed_live = {"slabs": 0, "tensors": 0, "norm": 0}
     from vllm_legacy_amd.distributed.xgmi_all_reduce import XgmiAllReduce
 
     def counted(name, key):
         inner = getattr(XgmiAllReduce, name)
 
         def wrapper(self, x, *a, **k):
-            fed[key(x)] += 1
+            fed_live[key(x)] += 1
             return inner(self, x, *a, **k)
         setattr(XgmiAllReduce, name, wrapper)
 
@@ -73,11 +73,40 @@ def main():
         max_prefill_seq_len=0, max_decode_seq_len=int(seq_lens.max()), query_start_loc=None,
         seq_start_loc=None, use_cuda_graph=False, context_lens_tensor=None,
         block_tables=torch.from_numpy(block_tables).to(dev))
+    ids_t, pos_t = torch.from_numpy(input_ids).to(dev), torch.from_numpy(positions).to(dev)
     with torch.inference_mode():
-        hidden = model(torch.from_numpy(input_ids).to(dev), torch.from_numpy(positions).to(dev),
-                       kv_caches, meta)
+        hidden = model(ids_t, pos_t, kv_caches, meta)
         logits = model.compute_logits(hidden)
     torch.cuda.synchronize()
+    fed = dict(fed_live)          # how the eager step fed the all-reduce (the capture below adds calls)
+
+    def fingerprint(h):
+        bits = h.contiguous().view(torch.int16).to(torch.int64).view(-1)
+        wts = torch.arange(bits.numel(), device=dev, dtype=torch.int64) % 65521 + 1
+        return int((bits * wts).sum().item())
+
+    def same_on_all_ranks(value):
+        got = [None] * world
+        dist.all_gather_object(got, value)
+        return all(g == got[0] for g in got)
+
+    # after the last all-reduce and the final norm every rank holds the same hidden state
+    assert same_on_all_ranks(fingerprint(hidden)), "ranks disagree after the eager step"
+    if os.environ.get("VLA_XGMI_ALLREDUCE") == "1":
+        # the same step replayed from a graph (the peer-memory all-reduce keeps its barrier counts
+        # on the device, so it can be captured; Gloo staging cannot): the same bits, on every rank
+        stream = torch.cuda.Stream(device=dev)
+        graph = torch.cuda.CUDAGraph()
+        buf = [None]
+        with torch.cuda.stream(stream), torch.inference_mode():
+            with torch.cuda.graph(graph, stream=stream, capture_error_mode="thread_local"):
+                buf[0] = model(ids_t, pos_t, kv_caches, meta)
+            dist.barrier()
+            graph.replay()
+            torch.cuda.synchronize()
+        assert torch.equal(buf[0].view(torch.int16), hidden.view(torch.int16)), \
+            "graph replay differs from the eager step"
+        assert same_on_all_ranks(fingerprint(buf[0])), "ranks disagree after the graph replay"
     xg = ps.get_tp_xgmi_all_reduce(dev)
     if os.environ.get("VLA_XGMI_ALLREDUCE") == "1":
         assert xg is not None and not xg.disabled and xg.error_count() == 0

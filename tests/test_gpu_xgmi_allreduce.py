@@ -74,3 +74,9 @@ def test_barrier_timeout_is_bounded_sticky_and_poisons_the_output():
     assert r0["errors"] > 0 and r0["polled_after"] > 0, r0
     assert 0.4 <= r0["wait_s"] <= 5.0, r0      # one bounded wait, then no more waiting
     assert r0["later_s"] <= 1.0, r0
+    # the late rank: no wait, no finite wrong sum, and its host knows
+    r1 = recs[1]
+    assert r1["late_all_nan"] and r1["late_errors"] > 0 and r1["late_polled"] > 0, r1
+    assert r1["late_s"] <= 1.0, r1
+    for r in (0, 1):
+        assert recs[r]["collective_check_ok"] is False and recs[r]["communicator_removed"], recs[r]

@@ -27,9 +27,13 @@
 // of the call in between only after every peer has finished reading in the call before.
 // A wait gives up after a bounded TIME (wall clock, default 10 s: a peer that is still repacking
 // weights or capturing a graph is merely late, not gone), so the kernel always terminates.  A
-// timeout can not go unnoticed: it is counted in `err`, which is sticky, and from then on every
-// call on this rank stores NaN in its output instead of a sum (the barrier counts of the ranks
-// may no longer agree, so nothing after a timeout can be trusted).
+// timeout can not go unnoticed on any rank: the rank that gives up counts it in `err` of EVERY
+// rank's region (its own and, by a system-scope atomic, each peer's).  `err` is sticky, a call
+// reads it when it starts and again before it ends, and a call that finds it set stores NaN in
+// its output instead of a sum -- so the late peer, which on arrival finds its flags already set
+// and would sail through both barriers gathering slices that were reduced without its data, is
+// poisoned just like the rank that waited for it (the barrier counts of the ranks may no longer
+// agree, so nothing after a timeout can be trusted anywhere).
 // Calls on one communicator must be issued in the same order with the same sizes by all ranks,
 // on one stream per rank.
 #include "vla_common.h"
@@ -88,7 +92,11 @@ __device__ __forceinline__ bool ar_barrier(const ArParams& P, uint32_t count, bo
            (int32_t)(__hip_atomic_load(mine, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) -
                      count) < 0) {
       if ((++polls & 1023u) == 0 && wall_clock64() - t0 > P.wait_ticks) {
-        atomicAdd(reinterpret_cast<uint32_t*>(P.region[P.rank] + AR_ERR_OFF), 1u);
+        // tell every rank, the absent one included: its region is mapped here whether or not
+        // its process is making progress
+        for (int r = 0; r < P.world; ++r)
+          __hip_atomic_fetch_add(reinterpret_cast<uint32_t*>(P.region[r] + AR_ERR_OFF), 1u,
+                                 __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         timed_out = 1;
         break;
       }
@@ -100,10 +108,15 @@ __device__ __forceinline__ bool ar_barrier(const ArParams& P, uint32_t count, bo
   return failed || timed_out != 0;
 }
 
-// Whether an earlier call on this rank lost a barrier (`err` is sticky).
+// Whether some rank has lost a barrier so far (`err` is sticky; peers bump it over the link).
+// One thread reads, the block agrees: other blocks of this launch, or a peer, may be adding to
+// `err` at this moment, and threads that each read for themselves could disagree and poison only
+// part of the block's output.
 __device__ __forceinline__ bool ar_failed_before(const ArParams& P) {
   const uint32_t* err = reinterpret_cast<const uint32_t*>(P.region[P.rank] + AR_ERR_OFF);
-  return __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+  const int bad = threadIdx.x == 0 &&
+                  __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0;
+  return __syncthreads_or(bad) != 0;
 }
 
 template <class S>
@@ -229,6 +242,7 @@ __global__ __launch_bounds__(AR_THREADS) void xgmi_two_shot_kernel(ArParams P, u
     const u32x4* src = reinterpret_cast<const u32x4*>(P.region[s] + half);
     ar_copy(out + base, src + base, first, len, stride);
   }
+  failed = ar_failed_before(P) || failed;   // a peer may have given up on this rank meanwhile
   if (failed) {  // a lost barrier: this block's part of the output is not a sum -- make it NaN
     // (each thread overwrites exactly the elements it has just gathered: no store of another
     // thread can land after the poison)
@@ -385,6 +399,7 @@ __global__ __launch_bounds__(AR_THREADS) void xgmi_two_shot_norm_kernel(
     }
     __syncthreads();                                   // red is reused by the next chunk
   }
+  failed = ar_failed_before(P) || failed;   // a peer may have given up on this rank meanwhile
   if (failed) {  // a lost barrier: the rows this block wrote are not what they claim to be
     const u32x4 nan = {AR_POISON, AR_POISON, AR_POISON, AR_POISON};
     for (int row = b; row < rows; row += G)
