@@ -1247,6 +1247,259 @@ __global__ __launch_bounds__(512) void q4_gemm_dma2_kernel(
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------
+// The LDS-DMA kernel for K-sliced layers: 128 x 32 wave tiles as in q4_gemm_dma_kernel, but the
+// workgroup is 4 column waves x 2 K parts (8 waves, two per SIMD, a 128 x 128 output tile): the two
+// parts' sums meet through LDS, so a layer that needs 256 workgroups' worth of K slices to fill the
+// chip writes HALF as many fp32 slabs as with one K range per workgroup -- and the slabs are what
+// these launches pay for: a 128 x 256 fp32 tile per workgroup leaves the chip at the HBM write
+// rate (qkv_proj 4096 x 6144 at batch 256, four slices: 1.4 us to the first tile, 14.6 us of loop,
+// 2.3 - 8 us until the last wave's 16 KiB x 8 are out), and the consumer reads them all back.
+// Each K part has its own x ring (its 4 waves fill and read it); the barrier is the workgroup's.
+__device__ __forceinline__ void glds_tile_kp(const uint32_t (&xoff)[4], uint64_t xbase, uint32_t xdst,
+                                             uint32_t woff, uint64_t wbase, uint32_t wdst,
+                                             const void* zsrc, uint32_t zdst) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %5\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %10\n\t"
+      "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %10\n\t"
+      "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %10\n\t"
+      "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, %10\n\t"
+      "s_mov_b32 m0, %7\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %6, %11\n\t"
+      "s_mov_b32 m0, %9\n\ts_nop 0\n\tglobal_load_lds_dword %8, off\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(xoff[0]), "v"(xoff[1]), "v"(xoff[2]), "v"(xoff[3]), "s"(xdst), "v"(woff), "s"(wdst),
+        "v"(zsrc), "s"(zdst), "s"(xbase), "s"(wbase)
+      : "memory");
+}
+
+template <int STAGES>
+struct Q4DmaKp {
+  static constexpr int XB = 128 * 128;          // x tile of one K part
+  static constexpr int WB = 4 * 1024;           // 1 KiB of weight words per wave
+  static constexpr int ZB = 4 * 256;            // 256 bytes of scales / zeros per wave
+  static constexpr int PART = XB + WB + ZB;     // one K part's share of a stage
+  static constexpr int STAGE = 2 * PART;
+  static constexpr int BYTES = STAGES * STAGE;
+  static constexpr int PER_TILE = 6;            // 4 x + 1 w + 1 zeros / scales
+  static_assert(BYTES >= 4 * 128 * 32 * 4, "the K parts' sums meet in the ring's memory");
+};
+
+template <int ZOFF, bool SPLIT, int STAGES, int D>
+__global__ __launch_bounds__(512) void q4_gemm_dma_kp_kernel(
+    const _Float16* __restrict__ x, const uint32_t* __restrict__ qw,
+    const uint32_t* __restrict__ qz, const _Float16* __restrict__ scales, void* __restrict__ outp,
+    int m, int n, int k, int group_size, int k_per_split) {
+  using L = Q4DmaKp<STAGES>;
+  constexpr int MT = 4;
+  static_assert(D >= 1 && STAGES >= D + 1 && STAGES <= 4 && L::PER_TILE * (D - 1) < 64, "ring depth");
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];   // the only LDS object: offset 0
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wn = wave & 3, wk = wave >> 2;                 // column wave, K part
+  const int h = lane >> 5, c = lane & 31;
+  const int n0 = blockIdx.x * 128, m0 = blockIdx.y * 128;
+  const int k_part = k_per_split / 2;                      // the host keeps this whole groups
+  const int k_begin = blockIdx.z * k_per_split + wk * k_part;
+  const int nsteps = k_part / TK;                          // the same for both parts
+  if (nsteps <= 0) return;
+  const int wcol0 = n0 + 32 * wn;                          // first column of this wave
+
+  // ---- what this lane fetches (columns past n: clamped to column 0, never stored)
+  uint32_t xoff[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int r = (wn * 4 + j) * 8 + (lane >> 3);
+    const int q = (lane & 7) ^ ((r >> 1) & 7);
+    xoff[j] = (uint32_t)(min(m0 + r, m - 1) * k + 8 * q) * 2u;       // M K < 2^30 (host check)
+  }
+  uint32_t wlane;
+  {
+    const int r = lane >> 3, col = wcol0 + 4 * (lane & 7);             // k8-row of the step, 4 columns
+    wlane = (uint32_t)(r * n + (col < n ? col : 0)) * 4u;
+  }
+  const unsigned char* zsrc;                               // walks one group per `zs_stride`
+  uint32_t zs_stride;
+  if ((lane & 31) < 16 || (lane & 31) >= 20) {             // scale pairs (lanes 20.. repeat them)
+    const int col = wcol0 + 2 * (lane & 15);
+    zsrc = reinterpret_cast<const unsigned char*>(scales) + (size_t)(col < n ? col : 0) * 2;
+    zs_stride = (uint32_t)n * 2u;
+  } else {                                                 // lanes 16..19 of each half: zero words
+    const int col = wcol0 + 8 * (lane & 3);
+    zsrc = reinterpret_cast<const unsigned char*>(qz) + (size_t)((col < n ? col : 0) >> 3) * 4;
+    zs_stride = (uint32_t)(n >> 3) * 4u;
+  }
+  zsrc += (size_t)(k_begin / group_size) * zs_stride;
+  uint64_t xbase = reinterpret_cast<uint64_t>(x) + (uint64_t)k_begin * 2u;
+  uint64_t wbase = reinterpret_cast<uint64_t>(qw) + (uint64_t)(k_begin >> 3) * (uint64_t)n * 4u;
+  const uint64_t wstep = (uint64_t)(TK / 8) * (uint64_t)n * 4u;
+  const int steps_per_group = group_size / TK;
+  int group_left = steps_per_group - (k_begin / TK) % steps_per_group;
+  const uint32_t part0 = (uint32_t)(wk * L::PART);
+  const uint32_t xdst0 = part0 + (uint32_t)(wn * 4096), wdst0 = part0 + (uint32_t)(L::XB + wn * 1024),
+                 zdst0 = part0 + (uint32_t)(L::XB + L::WB + wn * 256);
+  auto issue = [&](int stage) {
+    const uint32_t base = (uint32_t)(stage * L::STAGE);
+    glds_tile_kp(xoff, xbase, base + xdst0, wlane, wbase, base + wdst0, zsrc, base + zdst0);
+    xbase += TK * 2;
+    wbase += wstep;
+    if (--group_left == 0) {
+      group_left = steps_per_group;
+      zsrc += zs_stride;
+    }
+  };
+
+  // ---- what this lane reads: column c of the wave, k 8h .. 8h + 7 of each 16-deep slice
+  const int pbase = wk * L::PART;
+  const int woff = pbase + L::XB + wn * 1024 + h * 128 + c * 4;     // + 256 s
+  const int zsb = pbase + L::XB + L::WB + wn * 256;
+  const int soff = zsb + 4 * (c >> 1), zoff = zsb + 64 + 4 * (c >> 3);
+  const int zshift = 4 * (c & 7);
+  const uint32_t ssel = (c & 1) ? 0x03020302u : 0x01000100u;
+  const int aoff = pbase + c * 128;                        // + a 4096 + ((2 s + h) ^ cs) << 4
+  const int cs = (c >> 1) & 7;
+
+  f32x16 acc[MT];
+#pragma unroll
+  for (int a = 0; a < MT; ++a)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[a][i] = 0.f;
+
+  const f16x2 sixteenth = {(_Float16)0.0625f, (_Float16)0.0625f};
+  uint32_t c1024 = 0x64006400u;
+  asm volatile("" : "+v"(c1024));
+  constexpr uint32_t kLoMask = 0x000f000fu, kHiMask = 0x00f000f0u;
+  auto and_or = [](uint32_t a, uint32_t msk, uint32_t cc) { return (a & msk) | cc; };
+
+  struct Words { uint32_t w[4], sw, zw; };                 // a tile's raw words of this lane
+  struct Consts { f16x2 zc1, zc2, sc2; };
+  auto load_words = [&](const unsigned char* st, Words& d) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) d.w[s] = *reinterpret_cast<const uint32_t*>(st + woff + 256 * s);
+    d.sw = *reinterpret_cast<const uint32_t*>(st + soff);
+    d.zw = *reinterpret_cast<const uint32_t*>(st + zoff);
+  };
+  auto make_consts = [&](const Words& d) {
+    const uint32_t z = ((d.zw >> zshift) & 15u) + ZOFF;
+    Consts r;
+    r.zc1 = as_h2((z * 0x00010001u) | 0xE400E400u);
+    r.zc2 = as_h2((z * 0x00100010u) | 0xD400D400u);
+    r.sc2 = as_h2(__builtin_amdgcn_perm(d.sw, d.sw, ssel));
+    return r;
+  };
+  auto read_a = [&](const unsigned char* st, int s, u32x4 (&af)[MT]) {
+#pragma unroll
+    for (int a = 0; a < MT; ++a)
+      af[a] = *reinterpret_cast<const u32x4*>(st + aoff + a * 4096 + (((2 * s + h) ^ cs) << 4));
+  };
+  auto dequant = [&](uint32_t wv, const Consts& q) {
+    const uint32_t w8 = wv >> 8;
+    const f16x2 d0 = as_h2(and_or(wv, kLoMask, c1024)) + q.zc1;
+    const f16x2 d1 = __builtin_elementwise_fma(as_h2(and_or(wv, kHiMask, c1024)), sixteenth, q.zc2);
+    const f16x2 d2 = as_h2(and_or(w8, kLoMask, c1024)) + q.zc1;
+    const f16x2 d3 = __builtin_elementwise_fma(as_h2(and_or(w8, kHiMask, c1024)), sixteenth, q.zc2);
+    u32x4 bf;
+    bf[0] = as_u32(d0 * q.sc2);
+    bf[1] = as_u32(d1 * q.sc2);
+    bf[2] = as_u32(d2 * q.sc2);
+    bf[3] = as_u32(d3 * q.sc2);
+    return bf;
+  };
+  auto mma = [&](const u32x4 (&af)[MT], const u32x4& bf) {
+#pragma unroll
+    for (int a = 0; a < MT; ++a)
+      acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, bf),
+                                                      __builtin_bit_cast(f16x8, af[a]), acc[a], 0, 0,
+                                                      0);
+  };
+#define VLA_SB __builtin_amdgcn_sched_barrier(0)
+  Words wd;                                                // words of the tile about to be computed
+  auto step = [&](auto stage_c, int t) {
+    constexpr int ST = decltype(stage_c)::value;
+    const unsigned char* st = lds + ST * L::STAGE;
+    const unsigned char* stn = lds + ((ST + 1) % STAGES) * L::STAGE;
+    const Consts q = make_consts(wd);
+    u32x4 fa[MT], fb[MT];
+    read_a(st, 0, fa);
+    u32x4 b0 = dequant(wd.w[0], q);
+    VLA_SB;
+    read_a(st, 1, fb);
+    VLA_SB;
+    mma(fa, b0);
+    u32x4 b1 = dequant(wd.w[1], q);
+    VLA_SB;
+    if (t + D < nsteps) issue((ST + D) % STAGES);          // behind the first MFMAs, not before them
+    VLA_SB;
+    read_a(st, 2, fa);
+    VLA_SB;
+    mma(fb, b1);
+    b0 = dequant(wd.w[2], q);
+    VLA_SB;
+    read_a(st, 3, fb);
+    VLA_SB;
+    mma(fa, b0);
+    b1 = dequant(wd.w[3], q);
+    VLA_SB;
+    mma(fb, b1);
+    VLA_SB;
+    if (t + D < nsteps) wait_vmcnt<L::PER_TILE * (D - 1)>(); else wait_vmcnt<0>();
+    if (t + 1 < nsteps) load_words(stn, wd);               // this wave's own bytes: no barrier needed
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  };
+#undef VLA_SB
+
+  // ---- prologue: tiles 0 .. D - 1 requested, tile 0 landed
+#pragma unroll
+  for (int j = 0; j < D; ++j)
+    if (j < nsteps) issue(j);
+  if (D <= nsteps) wait_vmcnt<L::PER_TILE * (D - 1)>(); else wait_vmcnt<0>();
+  load_words(lds, wd);
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1 % STAGES>;
+  using I2 = std::integral_constant<int, 2 % STAGES>;
+  using I3 = std::integral_constant<int, 3 % STAGES>;
+  {
+    int t = 0;
+    for (; t + STAGES <= nsteps; t += STAGES) {
+      step(I0{}, t);
+      step(I1{}, t + 1);
+      if constexpr (STAGES >= 3) step(I2{}, t + 2);
+      if constexpr (STAGES >= 4) step(I3{}, t + 3);
+    }
+    if (t < nsteps) step(I0{}, t);
+    if (t + 1 < nsteps) step(I1{}, t + 1);
+    if constexpr (STAGES >= 4) {
+      if (t + 2 < nsteps) step(I2{}, t + 2);
+    }
+  }
+
+  // ---- the second K part hands its sums to the first through LDS (the ring is free: every wave
+  // has passed the last step's barrier with all its requests landed)
+  {
+    float* red = reinterpret_cast<float*>(lds) + wn * (MT * 16 * 64) + lane;
+    if (wk == 1) {
+#pragma unroll
+      for (int a = 0; a < MT; ++a)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) red[(a * 16 + i) * 64] = acc[a][i];
+    }
+    __syncthreads();
+    if (wk == 1) return;
+#pragma unroll
+    for (int a = 0; a < MT; ++a)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[a][i] += red[(a * 16 + i) * 64];
+  }
+  store_tile<SPLIT, MT>(acc, outp, m0 + c, m, wcol0 + 4 * h, n,
+                        SPLIT ? (int64_t)blockIdx.z * m : (int64_t)0);
+}
+
 // out[i] = fp16(sum over splits of slab[s][i]); 4 elements per thread
 __global__ __launch_bounds__(256) void q4_splitk_reduce_kernel(const float* __restrict__ slabs,
                                                                _Float16* __restrict__ out,
@@ -1331,11 +1584,12 @@ int launch_q4_gemm_skinny_grouped(const void* x, const int* x_rows, const void* 
 //    the slabs and their reduction exceeds what the shorter loop saves (K = 1024, N = 4096:
 //    1 slice 15.3 us, 4 slices 19.2 us).
 // VLA_Q4_TUNE="nw,splits[,mt]" overrides them (kernel studies).
-struct Q4Shape { int nw, splits, mt, kw; };   // kw: K parts inside a workgroup (small batches)
+struct Q4Shape { int nw, splits, mt, kw, kp; };   // kw: K parts inside a workgroup (small batches); kp: K parts of the 128-row LDS-DMA kernel (q4_gemm_dma_kp_kernel)
 
 static Q4Shape pick_shape(int m, int n, int k, int group) {
   Q4Shape s;
   s.kw = 1;
+  s.kp = 1;
   // Small batches (one or two 32-row tiles): the kernel streams the weights once, so the grid is
   // sized for bytes in flight -- 128-column workgroups and K slices until about one workgroup
   // per CU exists (the slabs of a 32-row batch are small) -- not for MFMA occupancy.
@@ -1405,6 +1659,24 @@ static Q4Shape pick_shape(int m, int n, int k, int group) {
       const int cap = atoi(e);
       if (cap >= 1 && want > cap) want = cap;
     }
+    // K-sliced 128-row launches: 128-column workgroups of two K parts that meet in LDS
+    // (q4_gemm_dma_kp_kernel) -- the same number of workgroups and of K steps per wave from half
+    // the slices, i.e. half the fp32 slabs written here and read back by the consumer.  Parts
+    // shorter than 8 K steps are all prologue.  VLA_Q4_KP=0 keeps one K range per workgroup.
+    static const bool kp_on = !(getenv("VLA_Q4_KP") && atoi(getenv("VLA_Q4_KP")) == 0);
+    if (kp_on && want > 1 && group % TK == 0) {
+      const int wgs_kp = ((n + 127) / 128) * mtiles;
+      int want_kp = 256 / wgs_kp;
+      if (want_kp > 8) want_kp = 8;
+      const int unit2 = 2 * (group > TK ? group : TK);
+      while (want_kp > 1 && (k / (want_kp * 2 * TK) < 8 || k % (want_kp * unit2) != 0)) --want_kp;
+      if (want_kp >= 1 && k % (want_kp * unit2) == 0 && k / (want_kp * 2 * TK) >= 8 &&
+          wgs_kp * want_kp >= 128) {
+        s.nw = 4;
+        s.kp = 2;
+        want = want_kp;
+      }
+    }
   }
   if (want < 1) want = 1;
   int kw = s.kw;
@@ -1420,9 +1692,14 @@ static Q4Shape pick_shape(int m, int n, int k, int group) {
     // 32- and 64-row tiles exist with four waves (128 columns) only: an override that shrinks
     // the tile must not leave the 256-column grid of the shape it replaced
     if (s.mt != 4) s.nw = 4;
+    s.kp = 1;
+    if (const char* e2 = getenv("VLA_Q4_TUNE_KP")) {    // with "4,splits" above: the K-part kernel
+      if (atoi(e2) == 2 && s.mt == 4 && s.nw == 4) s.kp = 2;
+    }
   }
-  const int unit = group > TK ? group : TK;  // a split must hold whole groups and whole K steps
+  const int unit = (group > TK ? group : TK) * s.kp;  // a split must hold whole groups and whole K steps (per K part)
   while (want > 1 && (k % (want * unit)) != 0) --want;
+  if (s.kp == 2 && k % (want * unit) != 0) s.kp = 1;
   s.splits = want;
   // K parts inside the workgroup: small row tiles of 128-column workgroups only, whole groups
   // (pairs of K steps where the per-group constants are fetched per pair) in every part
@@ -1460,6 +1737,26 @@ static hipError_t launch_dma2(dim3 grid, hipStream_t s, const _Float16* x, const
                               int group, int kps) {
   using L = Q4Dma2<ST>;
   auto fn = q4_gemm_dma2_kernel<Z, SP, ST, D>;
+  static std::atomic<uint64_t> ready{0};
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  if (!((ready.load(std::memory_order_acquire) >> (dev & 63)) & 1)) {
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, L::BYTES);
+    if (e != hipSuccess) return e;
+    ready.fetch_or(1ull << (dev & 63), std::memory_order_release);
+  }
+  hipLaunchKernelGGL(fn, grid, dim3(512), L::BYTES, s, x, qw, qz, sc, dst, m, n, k, group, kps);
+  return hipSuccess;
+}
+
+template <int Z, bool SP, int ST, int D>
+static hipError_t launch_dma_kp(dim3 grid, hipStream_t s, const _Float16* x, const uint32_t* qw,
+                                const uint32_t* qz, const _Float16* sc, void* dst, int m, int n, int k,
+                                int group, int kps) {
+  using L = Q4DmaKp<ST>;
+  auto fn = q4_gemm_dma_kp_kernel<Z, SP, ST, D>;
   static std::atomic<uint64_t> ready{0};
   int dev = 0;
   hipError_t e = hipGetDevice(&dev);
@@ -1560,6 +1857,8 @@ static int q4_gemm_run(const void* x, const int32_t* qweight, const int32_t* qze
       VLA_Q4_LAUNCH_KW(Z, SP, G2, 1);                                                          \
     else if (shape.mt == 2)                                                                    \
       VLA_Q4_LAUNCH_KW(Z, SP, G2, 2);                                                          \
+    else if (dma_ok && shape.kp == 2 && shape.nw == 4 && parts_ok && dma_env != 0)             \
+      VLA_HIP_CHECK((launch_dma_kp<Z, SP, 3, 2>(grid, s, VLA_Q4_ARGS)));                       \
     else if (dma_ok && dma_stages == 23 && shape.nw == 8 && parts_ok)                          \
       VLA_HIP_CHECK((launch_dma2<Z, SP, 3, 2>(grid, s, VLA_Q4_ARGS)));                         \
     else if (dma_ok && dma_stages == 3 && shape.nw == 8)                                       \
