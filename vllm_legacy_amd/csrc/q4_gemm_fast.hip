@@ -1662,7 +1662,12 @@ static Q4Shape pick_shape(int m, int n, int k, int group) {
     // K-sliced 128-row launches: 128-column workgroups of two K parts that meet in LDS
     // (q4_gemm_dma_kp_kernel) -- the same number of workgroups and of K steps per wave from half
     // the slices, i.e. half the fp32 slabs written here and read back by the consumer.  Parts
-    // shorter than 8 K steps are all prologue.  VLA_Q4_KP=0 keeps one K range per workgroup.
+    // shorter than 8 K steps are all prologue.  The price is in the requests: a wave of a K part
+    // issues four x pieces per K step where a wave of a 256-column workgroup issues two (each part
+    // stages its own x tile).  Kernel traces of the decode step at batch 256 (kernel / the consumer
+    // that sums its slabs, us): qkv_proj 4096 x 6144 22.3 / 10.7 -> 20.8 / 9.2, o_proj 4096 x 4096
+    // 16.7 / 7.8 -> ~15 / 6.4, down_proj 14336 x 4096 35.1 / 7.8 -> 33.7 / 6.4; everything of a
+    // layer but paged attention 214.1 -> 207.2.  VLA_Q4_KP=0 switches the K parts off.
     static const bool kp_on = !(getenv("VLA_Q4_KP") && atoi(getenv("VLA_Q4_KP")) == 0);
     if (kp_on && want > 1 && group % TK == 0) {
       const int wgs_kp = ((n + 127) / 128) * mtiles;
