@@ -379,6 +379,13 @@ int vla_moe_sort_pairs(const int64_t* selected_experts, const int* bucket_of, in
 int vla_moe_combine(const void* y, const float* routing_weights, const int64_t* selected_experts,
                     const int* pair_row, const int* bucket_of, int num_experts, int num_local,
                     int num_tokens, int top_k, int hidden, void* out, int dtype, void* stream);
+/* Act-ordered (desc_act) GPTQ experts, whose rows were sorted by group when they were shuffled
+ * (vllm/model_executor/layers/quantization/gptq.py:209-217): every sorted row's columns in its own
+ * expert's order, out[r, c] = x[src_row[r], perm[row_set[r], c]] (src_row NULL: row r itself),
+ * 16-bit elements, x rows x_stride elements apart, perm int32 [num_sets, cols], cols even.  One
+ * launch instead of an index tensor of [rows, cols] and two gathers. */
+int vla_moe_gather_perm(const void* x, const int* src_row, const int* row_set, const int* perm,
+                        void* out, int rows, int cols, int64_t x_stride, void* stream);
 
 /* ---- all-reduce over xGMI peer memory ---------------------------------------------------------- */
 

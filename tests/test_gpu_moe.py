@@ -316,3 +316,25 @@ def test_mixtral_decode_stack_matches_the_dense_expert_loop():
         graph.replay()
     torch.cuda.synchronize()
     assert torch.equal(out.float(), grouped)
+
+
+@pytest.mark.parametrize("rows,cols,sets", [(1, 64, 1), (37, 4096, 9), (512, 14336, 9)])
+def test_gather_perm_matches_the_index_tensor_formulation(rows, cols, sets):
+    """out[r, c] = x[src_row[r], perm[row_set[r], c]] against torch's index_select + gather through
+    a materialised [rows, cols] index tensor (what the act-order path used before), with and
+    without the row indirection, on a row-strided x."""
+    from vllm_legacy_amd import _custom_ops as ops
+    g = torch.Generator(device="cuda").manual_seed(rows + cols)
+    tokens = max(1, rows // 2)
+    wide = torch.empty((tokens, cols + 16), dtype=torch.float16, device="cuda").normal_(0, 1, generator=g)
+    x = wide[:, :cols]                                        # row stride cols + 16
+    perm = torch.stack([torch.randperm(cols, device="cuda", generator=g) for _ in range(sets)]).to(torch.int32)
+    row_set = torch.randint(0, sets, (rows, ), device="cuda", generator=g, dtype=torch.int32)
+    src = torch.randint(0, tokens, (rows, ), device="cuda", generator=g, dtype=torch.int32)
+    got = ops.moe_gather_perm(x, src, row_set, perm)
+    want = torch.gather(x.index_select(0, src.long()), 1, perm.long()[row_set.long()])
+    assert torch.equal(got, want)
+    if rows <= tokens * 2:
+        xs = x.index_select(0, src.long()).contiguous()
+        got2 = ops.moe_gather_perm(xs, None, row_set, perm)
+        assert torch.equal(got2, want)

@@ -644,6 +644,26 @@ def moe_combine(y: torch.Tensor, routing_weights: torch.Tensor, selected_experts
     return out
 
 
+def moe_gather_perm(x: torch.Tensor, src_row: Optional[torch.Tensor], row_set: torch.Tensor,
+                    perm: torch.Tensor) -> torch.Tensor:
+    """out[r, c] = x[src_row[r], perm[row_set[r], c]] (src_row None: row r): the rows of an MoE
+    block's sorted (token, expert) pairs with each row's columns in its own expert's act-order
+    permutation, in one launch.  x 16-bit [*, cols] (row-strided is fine), perm int32 [sets, cols]."""
+    _require_cuda(x, src_row, row_set, perm)
+    assert x.element_size() == 2 and x.stride(1) == 1
+    assert perm.dtype == torch.int32 and perm.is_contiguous() and perm.shape[1] == x.shape[1]
+    assert row_set.dtype == torch.int32 and row_set.is_contiguous()
+    if src_row is not None:
+        assert src_row.dtype == torch.int32 and src_row.is_contiguous() and src_row.numel() == row_set.numel()
+    rows, cols = row_set.numel(), x.shape[1]
+    out = torch.empty((rows, cols), dtype=x.dtype, device=x.device)
+    with torch.cuda.device(x.device):
+        check(_lib.lib().vla_moe_gather_perm(x.data_ptr(), _ptr(src_row), row_set.data_ptr(),
+                                             perm.data_ptr(), out.data_ptr(), rows, cols, x.stride(0),
+                                             _stream(x.device)), "moe_gather_perm")
+    return out
+
+
 class SplitKSlabs:
     """fp32 partial products [num_slabs, m, n] of an int4 GEMM whose K range was split, waiting
     for a consumer (fused_add_rms_norm_splitk / rotary_reshape_and_cache) to sum them."""

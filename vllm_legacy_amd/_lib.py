@@ -36,7 +36,7 @@ EXPORTS = [
     "vla_prefill_attention", "vla_prefix_prefill_attention", "vla_ar_region_bytes", "vla_ar_alloc_region",
     "vla_ar_free_region", "vla_ar_export", "vla_ar_import", "vla_ar_unimport", "vla_ar_create", "vla_ar_destroy",
     "vla_ar_all_reduce", "vla_ar_all_reduce_slabs", "vla_ar_all_reduce_add_rms_norm", "vla_ar_error_count", "vla_ar_error_count_async", "vla_q4_gemm_grouped", "vla_q4_gemm_grouped_workspace_bytes",
-    "vla_q4_gemm_grouped_gather", "vla_moe_route_topk", "vla_moe_gate_topk", "vla_moe_sort_pairs", "vla_moe_combine",
+    "vla_q4_gemm_grouped_gather", "vla_moe_route_topk", "vla_moe_gate_topk", "vla_moe_sort_pairs", "vla_moe_combine", "vla_moe_gather_perm",
     "vla_q4_gemm_packed_partial", "vla_q4_gemm_silu_and_mul_supported", "vla_q4_gemm_packed_silu_and_mul", "vla_rotary_reshape_and_cache", "vla_fused_add_rms_norm_splitk", "vla_silu_and_mul_splitk",
 ]
 
@@ -156,6 +156,7 @@ def lib():
         L.vla_moe_gate_topk.argtypes = [p, p, i, i, i, i, p, p, p, i, p]
         L.vla_moe_sort_pairs.argtypes = [p, p, i, i, i, i, p, p, p, p, p]
         L.vla_moe_combine.argtypes = [p, p, p, p, p, i, i, i, i, i, p, i, p]
+        L.vla_moe_gather_perm.argtypes = [p, p, p, p, p, i, i, i64, p]
         L.vla_ar_region_bytes.argtypes = [i64, p]
         L.vla_ar_alloc_region.argtypes = [i64, p]
         L.vla_ar_free_region.argtypes = [p]

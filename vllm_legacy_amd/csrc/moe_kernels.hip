@@ -331,6 +331,44 @@ extern "C" int vla_moe_sort_pairs(const int64_t* selected_experts, const int* bu
   return VLA_OK;
 }
 
+namespace vla {
+namespace {
+// out[r, c] = x[src_row[r] (or r), perm[row_set[r], c]], 16-bit elements.  One workgroup per row;
+// the permutation row is read coalesced, the gathered elements are 2-byte reads of one x row
+// (L2-resident: a row is a few KiB and is read cols times).
+__global__ __launch_bounds__(256) void moe_gather_perm_kernel(const uint16_t* __restrict__ x,
+                                                              const int* __restrict__ src_row,
+                                                              const int* __restrict__ row_set,
+                                                              const int* __restrict__ perm,
+                                                              uint16_t* __restrict__ out, int cols,
+                                                              int64_t x_stride) {
+  const int r = blockIdx.x;
+  const uint16_t* xr = x + (int64_t)(src_row ? src_row[r] : r) * x_stride;
+  const int* pr = perm + (int64_t)row_set[r] * cols;
+  uint16_t* o = out + (int64_t)r * cols;
+  for (int c = 2 * threadIdx.x; c < cols; c += 512) {
+    const int2 p = *reinterpret_cast<const int2*>(pr + c);
+    const uint32_t lo = xr[p.x], hi = xr[p.y];
+    *reinterpret_cast<uint32_t*>(o + c) = lo | (hi << 16);
+  }
+}
+}  // namespace
+}  // namespace vla
+
+extern "C" int vla_moe_gather_perm(const void* x, const int* src_row, const int* row_set,
+                                   const int* perm, void* out, int rows, int cols, int64_t x_stride,
+                                   void* stream) {
+  (void)hipGetLastError();
+  if (rows == 0) return VLA_OK;
+  if (!x || !row_set || !perm || !out || rows < 0 || cols <= 0 || cols % 2 || x_stride < cols ||
+      ((uintptr_t)out % 4) || ((uintptr_t)perm % 8))
+    return VLA_ERR_ARG;
+  hipLaunchKernelGGL(vla::moe_gather_perm_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream,
+                     (const uint16_t*)x, src_row, row_set, perm, (uint16_t*)out, cols, x_stride);
+  VLA_HIP_CHECK(hipGetLastError());
+  return VLA_OK;
+}
+
 extern "C" int vla_moe_combine(const void* y, const float* routing_weights,
                                const int64_t* selected_experts, const int* pair_row,
                                const int* bucket_of, int num_experts, int num_local, int num_tokens,

@@ -988,6 +988,34 @@ __device__ __forceinline__ void glds_tile2(const uint32_t (&xoff)[4], uint64_t x
       : "memory");
 }
 
+// The same requests in three groups (x pieces 0-1, x pieces 2-3, the weight and zero / scale
+// pieces), for issuing them between different MFMA groups of a step (-DVLA_Q4_SPREAD: a study of
+// where in the step the requests cost least).
+__device__ __forceinline__ void glds_x2(uint32_t xo0, uint32_t xo1, uint64_t xbase, uint32_t xdst) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %4\n\t"
+      "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %4\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(xo0), "v"(xo1), "s"(xdst), "s"(xbase)
+      : "memory");
+}
+__device__ __forceinline__ void glds_wz2(const uint32_t (&woff)[2], uint64_t wbase, uint32_t wdst,
+                                         const void* zsrc, uint32_t zdst) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %6 nt\n\t"
+      "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %6 nt\n\t"
+      "s_mov_b32 m0, %5\n\ts_nop 0\n\tglobal_load_lds_dword %4, off\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(woff[0]), "v"(woff[1]), "s"(wdst), "v"(zsrc), "s"(zdst), "s"(wbase)
+      : "memory");
+}
+
 template <int STAGES>
 struct Q4Dma2 {
   static constexpr int XB = 128 * 128;          // x tile of one K part
@@ -1065,6 +1093,23 @@ __global__ __launch_bounds__(512) void q4_gemm_dma2_kernel(
     if (--group_left == 0) {
       group_left = steps_per_group;
       zsrc += zs_stride;
+    }
+  };
+  // the same tile's requests in three groups (see glds_x2): part 0 and 1 = x, part 2 = the rest
+  auto issue_part = [&](int stage, int part) {
+    const uint32_t base = (uint32_t)(stage * L::STAGE);
+    if (part == 0) {
+      glds_x2(xoff[0], xoff[1], xbase, base + xdst0);
+    } else if (part == 1) {
+      glds_x2(xoff[2], xoff[3], xbase, base + xdst0 + 0x800);
+      xbase += TK * 2;
+    } else {
+      glds_wz2(wlane, wbase, base + wdst0, zsrc, base + zdst0);
+      wbase += wstep;
+      if (--group_left == 0) {
+        group_left = steps_per_group;
+        zsrc += zs_stride;
+      }
     }
   };
 
@@ -1157,7 +1202,11 @@ __global__ __launch_bounds__(512) void q4_gemm_dma2_kernel(
     mma2(fa, p0, p1);
     u32x4 r0 = dequant(wd.w[0][1], q0), r1 = dequant(wd.w[1][1], q1);
     VLA_SB;
+#ifdef VLA_Q4_SPREAD
+    if (t + D < nsteps) issue_part((ST + D) % STAGES, 2);  // weights first: they come from HBM
+#else
     if (t + D < nsteps) issue((ST + D) % STAGES);          // behind the first MFMAs, not before them
+#endif
     VLA_SB;
     read_a(st, 2, fa);
     VLA_SB;
@@ -1165,12 +1214,20 @@ __global__ __launch_bounds__(512) void q4_gemm_dma2_kernel(
     p0 = dequant(wd.w[0][2], q0);
     p1 = dequant(wd.w[1][2], q1);
     VLA_SB;
+#ifdef VLA_Q4_SPREAD
+    if (t + D < nsteps) issue_part((ST + D) % STAGES, 0);
+    VLA_SB;
+#endif
     read_a(st, 3, fb);
     VLA_SB;
     mma2(fa, p0, p1);
     r0 = dequant(wd.w[0][3], q0);
     r1 = dequant(wd.w[1][3], q1);
     VLA_SB;
+#ifdef VLA_Q4_SPREAD
+    if (t + D < nsteps) issue_part((ST + D) % STAGES, 1);
+    VLA_SB;
+#endif
     mma2(fb, r0, r1);
     VLA_SB;
     if (t + D < nsteps) wait_vmcnt<L::PER_TILE * (D - 1)>(); else wait_vmcnt<0>();
@@ -1180,6 +1237,9 @@ __global__ __launch_bounds__(512) void q4_gemm_dma2_kernel(
   };
 #undef VLA_SB
 
+#ifdef VLA_Q4_PRIO   // study: static priority for the second-dispatched half of the workgroup
+  if (wave >= 4) __builtin_amdgcn_s_setprio(1);
+#endif
   // ---- prologue: tiles 0 .. D - 1 requested, tile 0 landed
 #pragma unroll
   for (int j = 0; j < D; ++j)
@@ -1452,6 +1512,9 @@ __global__ __launch_bounds__(512) void q4_gemm_dma_kp_kernel(
   };
 #undef VLA_SB
 
+#ifdef VLA_Q4_PRIO
+  if (wave >= 4) __builtin_amdgcn_s_setprio(1);
+#endif
   // ---- prologue: tiles 0 .. D - 1 requested, tile 0 landed
 #pragma unroll
   for (int j = 0; j < D; ++j)

@@ -132,7 +132,7 @@ class QuantMixtralMoE(nn.Module):
                                                           device=lin.scales.device))
                         packed = (lin.qweight.data, lin.qzeros.data)
                         if lin.method.quant_config.desc_act:
-                            perms.append(lin.g_idx.data.long())     # argsort(g_idx) after first use
+                            perms.append(lin.g_idx.data.to(torch.int32))   # argsort(g_idx) after first use
                     else:
                         packed = getattr(lin, "_k_packed", None)
                         if packed is None:
@@ -144,7 +144,8 @@ class QuantMixtralMoE(nn.Module):
                 if perms:
                     # [local experts + 1, K]: the trailing bucket (rows of other ranks' experts,
                     # whose products are discarded) keeps its columns where they are
-                    perms.append(torch.arange(perms[0].numel(), device=perms[0].device))
+                    perms.append(torch.arange(perms[0].numel(), device=perms[0].device,
+                                              dtype=torch.int32))
                     perm = torch.stack(perms).contiguous()
                 return (torch.stack(pw).contiguous(), torch.stack(pz).contiguous(),
                         torch.stack(sc).contiguous(), perm)
@@ -181,15 +182,14 @@ class QuantMixtralMoE(nn.Module):
         # (a decode batch of up to 16 tokens takes the small-batch kernel on this bound)
         bound = min(pairs, num_tokens)
         if act_order:       # act-ordered experts: each row's columns in its expert's order
-            xs = hidden_states.index_select(0, sorted_token)
-            xs = torch.gather(xs, 1, w13[3][row_bucket.long()])
+            xs = ops.moe_gather_perm(hidden_states, sorted_token, row_bucket, w13[3])
             h = ops.q4_gemm_grouped(xs, w13[0], w13[1], w13[2], offsets, zo, bound)
         else:
             h = ops.q4_gemm_grouped(hidden_states, w13[0], w13[1], w13[2], offsets, zo, bound,
                                     x_rows=sorted_token)
         h = self.experts[self.expert_indicies[0]].act_fn(h)
         if act_order:
-            h = torch.gather(h, 1, w2[3][row_bucket.long()])
+            h = ops.moe_gather_perm(h, None, row_bucket, w2[3])
         # rows of other ranks' experts (the trailing bucket) are never read by the combine step
         y = ops.q4_gemm_grouped(h, w2[0], w2[1], w2[2], offsets, zo, bound, zero_outside=False)
         final = ops.moe_combine(y, routing_weights.contiguous(), selected_experts, pair_row,
@@ -214,12 +214,12 @@ class QuantMixtralMoE(nn.Module):
         zo = self._zero_offset
         row_expert = local[order]
         if w13[3] is not None:      # act-ordered experts: each row's columns in its expert's order
-            xs = torch.gather(xs, 1, w13[3][row_expert])
+            xs = ops.moe_gather_perm(xs, None, row_expert.to(torch.int32).contiguous(), w13[3])
         bound = min(rows, num_tokens)       # a token chooses an expert at most once
         h = ops.q4_gemm_grouped(xs, w13[0], w13[1], w13[2], offsets, zo, bound)
         h = self.experts[self.expert_indicies[0]].act_fn(h)
         if w2[3] is not None:
-            h = torch.gather(h, 1, w2[3][row_expert])
+            h = ops.moe_gather_perm(h, None, row_expert.to(torch.int32).contiguous(), w2[3])
         y = ops.q4_gemm_grouped(h, w2[0], w2[1], w2[2], offsets, zo, bound)
         # fp32 product, then the rounding to the model dtype, as two steps: written as one
         # in-place mixed multiply the compiler may fuse them into a single rounding
