@@ -721,7 +721,7 @@ def main():
                                                        "rank_of": args.rank_of, "world": world}:
             gemm_traffic = rec.get("bytes_per_layer")
         gemm = {
-            "kernel": "q4_gemm_dma2_kernel (gate_up) + q4_gemm_dma_kernel (qkv, o, down) + split-K reduce of one layer",
+            "kernel": "q4_gemm_dma2_kernel (gate_up) + q4_gemm_dma_kp_kernel (qkv, o, down) + split-K reduce of one layer",
             "bound": "mfma",
             "achieved": round(flops / (layer_ms * 1e-3) / 1e12, 1),
             "peak": MFMA_F16_PEAK_TFLOPS,

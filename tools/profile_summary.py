@@ -97,7 +97,7 @@ def gemm_traffic(fetch_csv, write_csv, dst, note):
     def per_kernel(path, counter):
         out = {}
         for r in csv.DictReader(open(path)):
-            if r["Counter"].startswith(counter) and re.search(r"q4_gemm_(m32|dma2?)_kernel", r["Kernel"]):
+            if r["Counter"].startswith(counter) and re.search(r"q4_gemm_(m32|dma2?|dma_kp)_kernel", r["Kernel"]):
                 out[r["Kernel"]] = (float(r["AvgBytes(corrected)"]), int(r["Dispatches"]))
         return out
 
