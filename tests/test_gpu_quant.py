@@ -347,3 +347,37 @@ def test_gptq_linear_method_partial_and_fused_forms_equal_apply(ops, desc_act, m
         ops.silu_and_mul(two, want)
         torch.cuda.synchronize()
         assert torch.equal(act.view(torch.int16), two.view(torch.int16))
+
+
+# The K-sliced 128-row launches (128 x 32 wave tiles, four column waves x two K parts per
+# workgroup, fp32 slabs summed by the reduction launch) at their edges: a last column tile that is
+# partly outside the matrix, a last row tile of a few rows, 64-deep groups, a contraction whose
+# slices hold an odd number of groups per part, and the GPTQ zero convention (stored zero - 1).
+@pytest.mark.parametrize("kind,m,k,n,group", [("awq", 200, 4096, 4136, 128), ("awq", 129, 4096, 6152, 64),
+                                              ("awq", 256, 14336, 4096, 128), ("awq", 70, 5120, 1032, 128),
+                                              ("gptq", 256, 4096, 6144, 128), ("gptq", 131, 3584, 8200, 128)])
+def test_k_part_launches_at_tile_edges(ops, kind, m, k, n, group):
+    rng = np.random.default_rng(m + n + k)
+    x = O.to_bits(rng.uniform(-1, 1, (m, k)).astype(np.float32), O.DT_F16)
+    if kind == "awq":
+        qw, qz, sc = _awq_weights(rng, k, n, group)
+        pw, pz = ops.awq_repack(_cuda(qw), _cuda(qz))
+        got = ops.q4_gemm_packed(_cuda(x, O.DT_F16), pw, pz, _cuda(sc, O.DT_F16), 0)
+        part = ops.q4_gemm_packed_partial(_cuda(x, O.DT_F16), pw, pz, _cuda(sc, O.DT_F16), 0)
+        w = O.awq_dequantize(qw, sc, qz)
+    else:
+        qw, qz, sc = _gptq_weights(rng, k, n, group)
+        gq = _cuda(qw.copy())
+        ops.gptq_shuffle(gq, torch.empty(0, dtype=torch.int32, device="cuda"), 4)
+        got = ops.gptq_gemm(_cuda(x, O.DT_F16), gq, _cuda(qz), _cuda(sc, O.DT_F16),
+                            torch.empty(0, dtype=torch.int32, device="cuda"), True, 4)
+        part = ops.q4_gemm_packed_partial(_cuda(x, O.DT_F16), gq, _cuda(qz), _cuda(sc, O.DT_F16), 1)
+        w = O.gptq_dequantize(qw, qz, sc)
+    torch.cuda.synchronize()
+    # the slabs a fused consumer would sum give the same bits as the library's own reduction
+    if isinstance(part, ops.SplitKSlabs):
+        assert torch.equal(part.reduce(), got)
+    cols = np.unique(np.concatenate([np.arange(0, n, 7), np.arange(max(0, n - 40), n)]))
+    want = O.gemm_f16(x, np.ascontiguousarray(w[:, cols]))
+    np.testing.assert_allclose(got[:, torch.from_numpy(cols).cuda()].float().cpu().numpy(),
+                               O.from_bits(want, O.DT_F16), rtol=3e-3, atol=8e-3)
