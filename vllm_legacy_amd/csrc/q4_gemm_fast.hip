@@ -2106,7 +2106,14 @@ static int q4_gemm_grouped_run(const void* x, const int* x_rows, const int32_t* 
   gp.z_stride = (int64_t)(k / group) * (n / 8);
   gp.s_stride = (int64_t)(k / group) * n;
   hipStream_t s = (hipStream_t)stream;
-  dim3 grid((n + 127) / 128, num_sets * gp.tiles_per_set, splits);
+  // 256-column workgroups (8 waves, one workgroup per CU) for wide layers whose sets fill their
+  // 128-row tiles: Mixtral-8x7B block at 1024 tokens (256 rows per expert on average) 1.00 ->
+  // 0.94 ms; at 64-512 tokens (16-128 rows per expert) 128-column workgroups, two per CU, stay
+  // ahead or level.  VLA_Q4_GROUPED_NW=4 / 8 forces either (kernel studies).
+  static const int grouped_nw = getenv("VLA_Q4_GROUPED_NW") ? atoi(getenv("VLA_Q4_GROUPED_NW")) : 0;
+  const bool nw8 = mt == 4 && n >= 8192 && splits == 1 &&
+                   (grouped_nw == 8 || (grouped_nw == 0 && total_rows >= 192 * num_sets));
+  dim3 grid(nw8 ? (n + 255) / 256 : (n + 127) / 128, num_sets * gp.tiles_per_set, splits);
   const int kps = k / splits;
   // sets of a few rows (an MoE block at 16-64 decode tokens): two K parts per workgroup (see
   // pick_shape), whole groups and at least eight K steps in each.  Mixtral-8x7B block from a
@@ -2127,7 +2134,10 @@ static int q4_gemm_grouped_run(const void* x, const int* x_rows, const int32_t* 
       dst, 0, n, k, group, kps, gp
 #define VLA_Q4G_G(Z, SP, G2)                                                                    \
   do {                                                                                          \
-    if (mt == 4)                                                                                \
+    if (mt == 4 && nw8)                                                                         \
+      hipLaunchKernelGGL((q4_gemm_m32_kernel<Z, SP, 8, 4, true, G2>), grid, dim3(512), 0, s,    \
+                         VLA_Q4G_ARGS);                                                         \
+    else if (mt == 4)                                                                           \
       hipLaunchKernelGGL((q4_gemm_m32_kernel<Z, SP, 4, 4, true, G2>), grid, dim3(256), 0, s,    \
                          VLA_Q4G_ARGS);                                                         \
     else if (kw == 2)                                                                           \
