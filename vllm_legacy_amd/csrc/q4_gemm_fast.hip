@@ -1096,7 +1096,7 @@ __global__ __launch_bounds__(512) void q4_gemm_dma2_kernel(
     }
   };
   // the same tile's requests in three groups (see glds_x2): part 0 and 1 = x, part 2 = the rest
-  auto issue_part = [&](int stage, int part) {
+  [[maybe_unused]] auto issue_part = [&](int stage, int part) {
     const uint32_t base = (uint32_t)(stage * L::STAGE);
     if (part == 0) {
       glds_x2(xoff[0], xoff[1], xbase, base + xdst0);
