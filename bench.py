@@ -661,7 +661,7 @@ def main():
         w_bytes = n_loc * 3 * cfg.hidden_size * cfg.intermediate_size // 2
         w_bytes += n_loc * 3 * (cfg.hidden_size * cfg.intermediate_size // 128) * 5 // 2   # zeros, scales
         moe = {
-            "kernel": "quantized sparse-MoE block: grouped int4 launches (w13, w2: q4_gemm_skinny_kernel up to 48 tokens, q4_gemm_m32_kernel above) + routing glue",
+            "kernel": "quantized sparse-MoE block: grouped int4 launches (w13, w2: q4_gemm_skinny_kernel up to 48 tokens, q4_gemm_mid_grouped_kernel up to ~200 rows per expert, q4_gemm_m32_kernel above) + routing glue",
             "bound": "hbm", "achieved": round(w_bytes / (moe_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": round(w_bytes / (moe_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
             "traffic": None, "algorithmic_bytes_per_block": w_bytes, "block_ms": round(moe_ms, 4),

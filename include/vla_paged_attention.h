@@ -61,6 +61,13 @@ int vla_set_attention_path(int mode);
  * never.  Results do not depend on it.  Process-wide (all threads, all devices), kept in a
  * relaxed atomic; the environment variable VLA_KV_LOAD_POLICY sets the initial value. */
 int vla_set_kv_load_policy(int mode);
+/* No counterpart in the reference.  Where the int4 GEMM kernel for row blocks of 17..80 rows
+ * (16-row MFMA blocks, x shared through LDS; csrc/q4_gemm_mid.hip) runs: 0 = grouped launches
+ * (vla_q4_gemm_grouped*: the experts of an MoE block) only (default), 1 = dense products of 17..80
+ * rows too (tests, kernel studies: the tile kernels are faster there), 2 = nowhere.  Results agree
+ * to the GEMM tolerance whichever kernel runs.  Process-wide, relaxed atomic; the environment
+ * variable VLA_Q4_MID sets the initial value. */
+int vla_set_q4_row_block_kernel(int mode);
 /* No counterpart in the reference; for measurement tooling.  Writes into buf the name of the
  * kernel instantiation a paged-attention call of this shape launches, spelled as a profiler's
  * kernel trace prints it (e.g. "pa_mfma_kernel<vla::F16, true, 128, 16, false, true>": model

@@ -381,3 +381,87 @@ def test_k_part_launches_at_tile_edges(ops, kind, m, k, n, group):
     want = O.gemm_f16(x, np.ascontiguousarray(w[:, cols]))
     np.testing.assert_allclose(got[:, torch.from_numpy(cols).cuda()].float().cpu().numpy(),
                                O.from_bits(want, O.DT_F16), rtol=3e-3, atol=8e-3)
+
+
+# Row blocks of 17..80 rows (16-row MFMA blocks against weights rebuilt once, x shared through LDS
+# by the four waves of a workgroup; K slices for narrow layers): every block count, row counts
+# that end inside a block, a last 256-column workgroup that is partly or wholly outside the
+# matrix for some of its waves, a contraction of a single 128-deep chunk, groups of two chunks,
+# and the GPTQ zero convention.
+@pytest.mark.parametrize("kind,m,k,n,group", [
+    ("awq", 17, 512, 256, 128), ("awq", 32, 128, 264, 128), ("awq", 33, 1024, 320, 128),
+    ("awq", 48, 4096, 4136, 128), ("awq", 64, 4096, 6144, 128), ("awq", 65, 2048, 840, 256),
+    ("awq", 80, 14336, 4096, 128), ("awq", 79, 4096, 28672, 128), ("awq", 75, 1536, 8, 128),
+    ("gptq", 40, 3584, 8200, 128), ("gptq", 81, 8192, 1280, 128)])
+def test_mid_row_block_launches(ops, kind, m, k, n, group):
+    ops.set_q4_row_block_kernel(1)         # dense products take the tile kernels by default
+    try:
+        _mid_row_block_case(ops, kind, m, k, n, group)
+    finally:
+        ops.set_q4_row_block_kernel(0)
+
+
+def _mid_row_block_case(ops, kind, m, k, n, group):
+    rng = np.random.default_rng(m + n + k)
+    x = O.to_bits(rng.uniform(-1, 1, (m, k)).astype(np.float32), O.DT_F16)
+    if kind == "awq":
+        qw, qz, sc = _awq_weights(rng, k, n, group)
+        pw, pz = ops.awq_repack(_cuda(qw), _cuda(qz))
+        got = ops.q4_gemm_packed(_cuda(x, O.DT_F16), pw, pz, _cuda(sc, O.DT_F16), 0)
+        part = ops.q4_gemm_packed_partial(_cuda(x, O.DT_F16), pw, pz, _cuda(sc, O.DT_F16), 0)
+        w = O.awq_dequantize(qw, sc, qz)
+    else:
+        qw, qz, sc = _gptq_weights(rng, k, n, group)
+        gq = _cuda(qw.copy())
+        ops.gptq_shuffle(gq, torch.empty(0, dtype=torch.int32, device="cuda"), 4)
+        got = ops.gptq_gemm(_cuda(x, O.DT_F16), gq, _cuda(qz), _cuda(sc, O.DT_F16),
+                            torch.empty(0, dtype=torch.int32, device="cuda"), True, 4)
+        part = ops.q4_gemm_packed_partial(_cuda(x, O.DT_F16), gq, _cuda(qz), _cuda(sc, O.DT_F16), 1)
+        w = O.gptq_dequantize(qw, qz, sc)
+    torch.cuda.synchronize()
+    assert got.shape == (m, n)
+    if isinstance(part, ops.SplitKSlabs):
+        assert torch.equal(part.reduce(), got)
+    cols = np.unique(np.concatenate([np.arange(0, n, 7), np.arange(max(0, n - 40), n)]))
+    want = O.gemm_f16(x, np.ascontiguousarray(w[:, cols]))
+    np.testing.assert_allclose(got[:, torch.from_numpy(cols).cuda()].float().cpu().numpy(),
+                               O.from_bits(want, O.DT_F16), rtol=3e-3, atol=8e-3)
+
+
+@pytest.mark.parametrize("counts,tail,gather", [([70, 20, 80, 0, 81, 1, 16, 33], 0, False),
+                                                ([64] * 8, 5, False), ([31, 90, 2, 77, 48, 65, 80, 17], 3, True)])
+def test_grouped_mid_row_blocks(ops, counts, tail, gather):
+    """The grouped form of the 17..80-row kernel (an MoE block's experts at a few dozen rows each):
+    sets with no rows, with exactly one 80-row tile, with one row more than a tile (a second pass
+    over the set's weights), and the row gather."""
+    rng = np.random.default_rng(sum(counts) + tail)
+    ic, oc, group, sets = 512, 8192, 128, len(counts)
+    ws = [_awq_weights(rng, ic, oc, group) for _ in range(sets)]
+    packed = [ops.awq_repack(_cuda(qw), _cuda(qz)) for qw, qz, _ in ws]
+    pw = torch.stack([p[0] for p in packed]).contiguous()
+    pz = torch.stack([p[1] for p in packed]).contiguous()
+    sc = torch.stack([_cuda(w[2], O.DT_F16) for w in ws]).contiguous()
+    rows = sum(counts) + tail
+    offsets = torch.tensor(np.concatenate([[0], np.cumsum(counts)]), dtype=torch.int32, device="cuda")
+    if gather:
+        src = O.to_bits(rng.uniform(-1, 1, (200, ic)).astype(np.float32), O.DT_F16)
+        idx = rng.integers(0, 200, rows).astype(np.int32)
+        x = src[idx]
+        got = ops.q4_gemm_grouped(_cuda(src, O.DT_F16), pw, pz, sc, offsets, 0, max(counts),
+                                  x_rows=torch.from_numpy(idx).cuda())
+    else:
+        x = O.to_bits(rng.uniform(-1, 1, (rows, ic)).astype(np.float32), O.DT_F16)
+        got = ops.q4_gemm_grouped(_cuda(x, O.DT_F16), pw, pz, sc, offsets, 0, max(counts))
+    torch.cuda.synchronize()
+    got = got.float().cpu().numpy()
+    cols = np.arange(0, oc, 5)
+    start = 0
+    for (qw, qz, s), c in zip(ws, counts):
+        if c:
+            w = np.ascontiguousarray(O.awq_dequantize(qw, s, qz)[:, cols])
+            want = O.gemm_f16(x[start:start + c], w)
+            np.testing.assert_allclose(got[start:start + c][:, cols], O.from_bits(want, O.DT_F16),
+                                       rtol=3e-3, atol=4e-3)
+        start += c
+    if not gather:
+        assert not got[start:].any()

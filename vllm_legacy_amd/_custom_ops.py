@@ -862,6 +862,12 @@ def set_attention_path(mode: int) -> None:
     check(_lib.lib().vla_set_attention_path(mode))
 
 
+def set_q4_row_block_kernel(mode: int) -> None:
+    """Where the int4 GEMM kernel for row blocks of 17..80 rows runs: 0 grouped launches only
+    (default), 1 dense products of 17..80 rows too (tests, kernel studies), 2 nowhere."""
+    check(_lib.lib().vla_set_q4_row_block_kernel(mode))
+
+
 def set_kv_load_policy(mode: int) -> None:
     """Cache policy of the attention kernel's K / V loads: 0 by size (default), 1 always
     nontemporal, 2 never.  A cache that stays resident between launches (a benchmark over a small

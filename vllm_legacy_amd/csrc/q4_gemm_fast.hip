@@ -1629,6 +1629,16 @@ bool q4_skinny_silu_ok(int m, int n, int k, int group);
 int launch_q4_gemm_skinny_silu(const void* x, const void* qw, const void* qz, const void* scales,
                                void* out, int m, int n, int k, int group, int zero_offset,
                                hipStream_t s);
+// q4_gemm_mid.hip: row blocks of 17..96 rows
+bool q4_mid_shape(int m, int n, int k, int group, int* splits);
+int launch_q4_gemm_mid(const void* x, const void* qw, const void* qz, const void* scales, void* dst,
+                       int m, int n, int k, int group, int zero_offset, int splits, hipStream_t s);
+int q4_mid_grouped_splits(int total_rows, int num_sets, int n, int k, int group);
+int q4_mid_set_mode(int mode);
+int launch_q4_gemm_mid_grouped(const void* x, const int* x_rows, const void* qw, const void* qz,
+                               const void* scales, void* dst, const int* row_offsets, int num_sets,
+                               int total_rows, int max_rows_per_set, int n, int k, int group,
+                               int zero_offset, int splits, hipStream_t s);
 bool q4_skinny_grouped_ok(int max_rows_per_set, int total_rows, int num_sets, int n, int k,
                           int group);
 int launch_q4_gemm_skinny_grouped(const void* x, const int* x_rows, const void* qw, const void* qz,
@@ -1839,12 +1849,18 @@ static hipError_t launch_dma_kp(dim3 grid, hipStream_t s, const _Float16* x, con
   return hipSuccess;
 }
 
+extern "C" int vla_set_q4_row_block_kernel(int mode) {
+  return q4_mid_set_mode(mode) ? VLA_ERR_ARG : VLA_OK;
+}
+
 extern "C" int64_t vla_q4_gemm_workspace_bytes(int m, int n, int k, int group) {
   if (m <= 0 || n <= 0 || k <= 0 || group <= 0) return 0;
   int sk_nwv = 0, sk_splits = 0, sk_cs = 0;
+  int md_splits = 0;
   const int s = q4_skinny_shape(m, n, k, group, &sk_nwv, &sk_splits, &sk_cs)
                     ? sk_splits
-                    : pick_shape(m, n, k, group).splits;
+                    : q4_mid_shape(m, n, k, group, &md_splits) ? md_splits
+                                                               : pick_shape(m, n, k, group).splits;
   return s > 1 ? (int64_t)s * m * n * 4 : 0;
 }
 
@@ -1888,6 +1904,25 @@ static int q4_gemm_run(const void* x, const int32_t* qweight, const int32_t* qze
       VLA_HIP_CHECK(hipGetLastError());
     } else if (sk_splits > 1 && num_slabs) {
       *num_slabs = sk_splits;
+    }
+    return VLA_OK;
+  }
+  int md_splits = 0;
+  if (q4_mid_shape(m, n, k, group, &md_splits)) {
+    // 17..96 rows: one pass over the weights with x shared through LDS, see q4_gemm_mid.hip
+    if (md_splits > 1 && (!workspace || workspace_bytes < (int64_t)md_splits * m * n * 4 ||
+                          ((uintptr_t)workspace % 16) || ((int64_t)m * n) % 4))
+      md_splits = 1;
+    launch_q4_gemm_mid(x, qweight, qzeros, scales, md_splits > 1 ? workspace : out, m, n, k, group,
+                       zero_offset, md_splits, s);
+    VLA_HIP_CHECK(hipGetLastError());
+    if (md_splits > 1 && reduce) {
+      const int64_t elems = (int64_t)m * n;
+      hipLaunchKernelGGL(q4_splitk_reduce_kernel, dim3((unsigned)((elems / 4 + 255) / 256)),
+                         dim3(256), 0, s, (const float*)workspace, (_Float16*)out, elems, md_splits);
+      VLA_HIP_CHECK(hipGetLastError());
+    } else if (md_splits > 1 && num_slabs) {
+      *num_slabs = md_splits;
     }
     return VLA_OK;
   }
@@ -2039,9 +2074,7 @@ extern "C" int vla_awq_repack(const int32_t* qweight, const int32_t* qzeros, int
 // Grouped product for small row blocks (MoE experts at decode): 64-row tiles, 128-column
 // workgroups, K split into at most 8 slices until the launch has about two workgroups per CU per
 // expected active tile; the slabs are summed by the reduction kernel.
-extern "C" int64_t vla_q4_gemm_grouped_workspace_bytes(int total_rows, int n, int k, int group,
-                                                       int num_sets) {
-  if (total_rows <= 0 || n <= 0 || k <= 0 || group <= 0 || num_sets <= 0) return 0;
+static int q4_grouped_tile_splits(int total_rows, int n, int k, int group, int num_sets) {
   const int wgs = ((n + 127) / 128) * num_sets;
   int want = (512 + wgs - 1) / wgs;
   if (want > 8) want = 8;
@@ -2049,6 +2082,18 @@ extern "C" int64_t vla_q4_gemm_grouped_workspace_bytes(int total_rows, int n, in
   if (want < 1) want = 1;
   const int unit = group > TK ? group : TK;
   while (want > 1 && (k % (want * unit)) != 0) --want;
+  (void)total_rows;
+  return want;
+}
+
+// the larger of what the two grouped kernels (128-row tiles, 80-row tiles of 16-row blocks) would
+// use for this product; each takes its own slice count out of it
+extern "C" int64_t vla_q4_gemm_grouped_workspace_bytes(int total_rows, int n, int k, int group,
+                                                       int num_sets) {
+  if (total_rows <= 0 || n <= 0 || k <= 0 || group <= 0 || num_sets <= 0) return 0;
+  int want = q4_grouped_tile_splits(total_rows, n, k, group, num_sets);
+  const int mid = q4_mid_grouped_splits(total_rows, num_sets, n, k, group);
+  if (mid > want) want = mid;
   return want > 1 ? (int64_t)want * total_rows * n * 4 : 0;
 }
 
@@ -2079,11 +2124,30 @@ static int q4_gemm_grouped_run(const void* x, const int* x_rows, const int32_t* 
     VLA_HIP_CHECK(hipGetLastError());
     return VLA_OK;
   }
-  const int64_t need = vla_q4_gemm_grouped_workspace_bytes(total_rows, n, k, group, num_sets);
-  int splits = need ? (int)(need / ((int64_t)total_rows * n * 4)) : 1;
-  if (splits > 1 && (!workspace || workspace_bytes < need || ((uintptr_t)workspace % 16) ||
-                     ((int64_t)total_rows * n) % 4))
-    splits = 1;
+  const bool ws_ok = workspace && ((uintptr_t)workspace % 16) == 0 && ((int64_t)total_rows * n) % 4 == 0;
+  if (int md = q4_mid_grouped_splits(total_rows, num_sets, n, k, group)) {
+    // a few dozen rows per set: 80-row tiles of 16-row blocks with x shared through LDS, one
+    // launch over all sets; K slices for narrow products
+    const int64_t md_need = (int64_t)md * total_rows * n * 4;
+    if (md == 1 || (ws_ok && workspace_bytes >= md_need)) {
+      hipStream_t ms = (hipStream_t)stream;
+      if (md > 1 && clear_slabs) VLA_HIP_CHECK(hipMemsetAsync(workspace, 0, (size_t)md_need, ms));
+      launch_q4_gemm_mid_grouped(x, x_rows, qweight, qzeros, scales, md > 1 ? workspace : out,
+                                 row_offsets, num_sets, total_rows, max_rows_per_set, n, k, group,
+                                 zero_offset, md, ms);
+      VLA_HIP_CHECK(hipGetLastError());
+      if (md > 1) {
+        const int64_t elems = (int64_t)total_rows * n;
+        hipLaunchKernelGGL(q4_splitk_reduce_kernel, dim3((unsigned)((elems / 4 + 255) / 256)),
+                           dim3(256), 0, ms, (const float*)workspace, (_Float16*)out, elems, md);
+        VLA_HIP_CHECK(hipGetLastError());
+      }
+      return VLA_OK;
+    }
+  }
+  int splits = q4_grouped_tile_splits(total_rows, n, k, group, num_sets);
+  const int64_t need = splits > 1 ? (int64_t)splits * total_rows * n * 4 : 0;
+  if (splits > 1 && (!ws_ok || workspace_bytes < need)) splits = 1;
   Q4Groups gp{};
   gp.row_offsets = row_offsets;
   gp.x_rows = x_rows;
