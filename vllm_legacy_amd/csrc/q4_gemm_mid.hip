@@ -28,16 +28,20 @@
 // waits for the x pieces alone and leaves both younger chunks of weight words in flight.
 //
 // Where the time goes (Mixtral-8x7B w1|w3, 8 experts x 4096 -> 28672, 256 tokens = 64 rows per
-// expert, 172-210 us; diagnostic builds -DVLA_MID_ABL, counter passes tools/exp/pmc_grouped.sh):
-// the matrix pipe is 39 % busy (81 us of MFMAs), the vector port 43 % (52 us of dequantisation),
-// the weights are 72 us of HBM time, and the three barely overlap -- without dequantisation and
-// weight requests the loop runs at the MFMA pace (75 us), each of the two adds its own time.  A
-// 16x16x32 MFMA holds the SIMD's vector issue for 8 of its 16 cycles, so the two waves of a SIMD
-// share one port that is taken for 920 (vector) + 8 x 64..80 (MFMA) cycles per chunk and wave;
-// and with two waves per SIMD (250 registers) a wave that waits for memory leaves the port to one
-// wave.  Measured without effect: weight words three or four chunks ahead, x through three LDS
-// buffers, eight waves per workgroup (half the x traffic), an MFMA / vector interleave by
-// sched_group_barrier, x rows at a non-power-of-two pitch.
+// expert, 172-210 us; diagnostic builds -DVLA_MID_ABL / -DVLA_MID_STAMP, counter passes
+// tools/exp/pmc_grouped.sh): the vector issue port of a SIMD.  A 16x16x32 MFMA holds the port for 8
+// of its 16 cycles, so a chunk costs a wave 920 cycles of vector instructions (13 per packed word)
+// plus 8 x 64..80 cycles of MFMA issue, ~1 430-1 560 cycles, beside ~150 of scalar, LDS and
+// memory instructions; in-kernel stamps show the two waves of a SIMD each taking ~3 200 cycles per
+// chunk (arithmetic 2 140, issuing the ten requests 590 -- the CU's eight waves queue at its
+// 64 B/clk texture path --, parking x 260, barrier 120), i.e. 1 600 cycles of SIMD time per wave
+// and chunk: the port is full, at the ~1.6 GHz the part holds under this load.  Counters agree
+// (matrix pipe 39 % busy, vector ALU 43 %, both through the one port).  What is left is fewer
+// instructions per weight -- 32x32x16 MFMAs would halve the MFMA share of the port at the price of
+// 32-row granularity (~9 % on this shape, not built); the 13 instructions per word are what the
+// reference's rounding costs.  Measured without effect: weight words three or four chunks ahead,
+// x through three LDS buffers, eight waves per workgroup (half the x traffic), an MFMA / vector
+// interleave by sched_group_barrier, x rows at a non-power-of-two pitch.
 //
 // GROUPED: several weight sets in one launch (blockIdx.y = set, blockIdx.z = 80-row tile of the
 // set, row ranges and the optional row gather read on the device); a workgroup runs the body built
@@ -276,14 +280,35 @@ __device__ __forceinline__ void q4_mid_body(
   __syncthreads();
   int t = 0;
   uint32_t rd = 0;
+#ifdef VLA_MID_STAMP   // diagnostic build: shader cycles per phase of the K loop, summed per wave
+  uint64_t st_park = 0, st_issue = 0, st_math = 0, st_bar = 0;
+  const uint64_t st_loop0 = __builtin_amdgcn_s_memtime();
+#define VLA_MID_T(v) const uint64_t v = __builtin_amdgcn_s_memtime()
+#else
+#define VLA_MID_T(v)
+#endif
   auto iter = [&](MdChunk& cur, MdChunk& nxt) {
+    VLA_MID_T(ta);
     storex(rd ^ XB);
+#ifdef VLA_MID_STAMP
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+    VLA_MID_T(tb);
     loadx();
     loadw(nxt);
     __builtin_amdgcn_sched_barrier(0);          // the requests stay ahead of the chunk's arithmetic
+    VLA_MID_T(tc);
     compute(cur, rd);
+#ifdef VLA_MID_STAMP
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+    VLA_MID_T(td);
 #if !(VLA_MID_ABL & 16)
     __syncthreads();
+#endif
+    VLA_MID_T(te);
+#ifdef VLA_MID_STAMP
+    st_park += tb - ta; st_issue += tc - tb; st_math += td - tc; st_bar += te - td;
 #endif
     rd ^= XB;
     ++t;
@@ -296,6 +321,18 @@ __device__ __forceinline__ void q4_mid_body(
   for (int u = 0; u < NB - 1; ++u)
     if (t < nch) iter(ring[u], ring[(u + NB - 1) % NB]);
 
+#ifdef VLA_MID_STAMP
+  {
+    const uint64_t st_loop1 = __builtin_amdgcn_s_memtime();
+    if (lane == 0 && (wave == 0 || wave == NWV - 1) &&
+        ((blockIdx.x + 5 * blockIdx.y + 11 * blockIdx.z) % 97) == 0)
+      printf("stampmid wg %d,%d,%d wave %d rb %d chunks %d start %llu loop %llu park %llu issue %llu math %llu barrier %llu\n",
+             blockIdx.x, blockIdx.y, blockIdx.z, wave, RB, nch,
+             (unsigned long long)(st_loop0 % 1000000000ull), (unsigned long long)(st_loop1 - st_loop0),
+             (unsigned long long)st_park, (unsigned long long)st_issue, (unsigned long long)st_math,
+             (unsigned long long)st_bar);
+  }
+#endif
   // ---- lane (c, g) holds, for x row 16 r + c, the 16 adjacent columns n0 + 16 g + 4 i + j =
   // acc[r][j][i]
   const int oc = n0 + 16 * g;
