@@ -70,8 +70,9 @@ int vla_set_kv_load_policy(int mode);
 int vla_set_q4_row_block_kernel(int mode);
 /* No counterpart in the reference; for measurement tooling.  Writes into buf the name of the
  * kernel instantiation a paged-attention call of this shape launches, spelled as a profiler's
- * kernel trace prints it (e.g. "pa_mfma_kernel<vla::F16, true, 128, 16, false, true>": model
- * dtype, fp8 cache, head size, block size, partitioned, nontemporal K/V loads; or
+ * kernel trace prints it (e.g. "pa_mfma_kernel<vla::F16, true, 128, 16, false, true, false>": model
+ * dtype, fp8 cache, head size, block size, partitioned, nontemporal K/V loads, rotary + cache
+ * write fused in (true only from vla_rope_paged_attention); or
  * "pa_generic_kernel"), so that a stored profile can be matched to the kernel a run launches.
  * Assumes 16-byte aligned cache pointers and strides.  partitioned: 0 = V1, 1 = V2. */
 int vla_paged_attention_kernel_name(char* buf, int buf_len, int num_seqs, int num_kv_heads,
@@ -489,6 +490,34 @@ int vla_rotary_reshape_and_cache(const int64_t* positions, void* query, void* ke
                                  int is_neox, int dtype, int kv_dtype, float kv_scale,
                                  const float* slabs, int num_slabs, int64_t slab_stride,
                                  int64_t slab_row, int q_col, int k_col, int v_col, void* stream);
+
+/* The same step carried into the attention launch of a decode batch: rotary_embedding
+ * (csrc/ops.h:38-40, NeoX pairing over the whole head), reshape_and_cache (csrc/cache.h:15-25) of
+ * the rotated key and of value, then paged_attention_v1 (csrc/ops.h:5-12; exp_sums, max_logits and
+ * tmp_out NULL) or paged_attention_v2 (csrc/ops.h:14-30) over the cache including the new token,
+ * in one launch (two for V2: its reduce).  Token t of the step is sequence t.  The cache bytes and
+ * `out` equal those of vla_rotary_reshape_and_cache followed by vla_paged_attention_v1 / _v2 bit
+ * for bit; the rotated query and key are NOT written back to query / key.  query / key / value:
+ * the unrotated rows (model dtype, row strides in elements), or NULL with `slabs` as above.
+ * vla_rope_paged_attention_supported says whether a shape is taken (head size 128, rot_dim ==
+ * head size, NeoX, at most 16 query heads per KV head, block size 8 / 16 / 32, fp16 / bf16);
+ * anything else returns VLA_ERR_ARG and the caller runs the separate entry points.
+ * write_kv == 0: key and value of the step are in the cache already (vla_rotary_reshape_and_cache
+ * with num_heads 0 rotates and caches them alone) and only the query is rotated here -- the form
+ * for launches that saturate HBM, where stores scattered into the read stream cost more than the
+ * launch they save (batch 256 x 4096 tokens: 375 us with the write inside, 345 + 6 without). */
+int vla_rope_paged_attention_supported(int num_heads, int num_kv_heads, int head_size, int rot_dim,
+                                       int is_neox, int block_size, int dtype);
+int vla_rope_paged_attention(
+    void* out, float* exp_sums, float* max_logits, void* tmp_out, const void* query,
+    const void* key, const void* value, int64_t q_stride, int64_t k_stride, int64_t v_stride,
+    const int64_t* positions, const void* cos_sin_cache, int rot_dim, int is_neox, void* key_cache,
+    void* value_cache, const int64_t* slot_mapping, const float* slabs, int num_slabs,
+    int64_t slab_stride, int64_t slab_row, int q_col, int k_col, int v_col, int num_seqs,
+    int num_heads, int num_kv_heads, int head_size, int block_size, float scale,
+    const int* block_tables, const int* seq_lens, int max_num_blocks_per_seq, int max_seq_len,
+    const float* alibi_slopes, int64_t kv_block_stride, int64_t kv_head_stride, int dtype,
+    int kv_dtype, float kv_scale, const int* seq_order, int write_kv, void* stream);
 
 /* fused_add_rms_norm (csrc/ops.h:35-36) whose `input` arrives as split-K slabs
  * [num_slabs][num_tokens][hidden_size] fp32: x = model_dtype(sum of slabs);

@@ -49,6 +49,14 @@ from tests import e2e_oracle as E
 from tests import pa_testlib as T
 
 pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def _separate_launches(monkeypatch):
+    """These tests hook the attention module to look at every step of a layer, so the decode step
+    keeps rotary embedding / cache write and attention as separate launches; the launch that does
+    all three equals them bit for bit (tests/test_gpu_rope_attention.py, also on a whole step)."""
+    monkeypatch.setenv("VLA_FUSE_ROPE_ATTN", "0")
 DT = O.DT_F16
 
 from tests.e2e_gpu import (awq_dense, capture_hooks, check_written_cache, compare_step,  # noqa: E402

@@ -735,9 +735,10 @@ def rotary_reshape_and_cache(positions: torch.Tensor, query: torch.Tensor, key: 
                              value: torch.Tensor, head_size: int, cos_sin_cache: torch.Tensor,
                              is_neox: bool, key_cache, value_cache, slot_mapping: torch.Tensor,
                              kv_cache_dtype: str, kv_scale: float,
-                             slabs: Optional[SplitKSlabs] = None) -> None:
+                             slabs: Optional[SplitKSlabs] = None, skip_query: bool = False) -> None:
     """rotary_embedding(positions, query, key, ...) followed by reshape_and_cache(key, value, ...)
-    in one launch.  query [T, Hq*D], key/value [T, Hkv*D] may be strided row views of one qkv
+    in one launch.  skip_query: the query is left alone (rope_paged_attention(write_kv=False)
+    rotates it inside the attention launch).  query [T, Hq*D], key/value [T, Hkv*D] may be strided row views of one qkv
     tensor.  With `slabs` (the unreduced qkv projection, columns laid out q | k | v) the three
     tensors are outputs only."""
     _require_cuda(positions, query, key, value, cos_sin_cache, slot_mapping)
@@ -756,11 +757,76 @@ def rotary_reshape_and_cache(positions: torch.Tensor, query: torch.Tensor, key: 
         check(_lib.lib().vla_rotary_reshape_and_cache(
             positions.data_ptr(), query.data_ptr(), key.data_ptr(), value.data_ptr(),
             cos_sin_cache.data_ptr(), key_cache.data_ptr(), value_cache.data_ptr(),
-            slot_mapping.data_ptr(), t, hq, hkv, head_size, cos_sin_cache.shape[1], q2.stride(0),
+            slot_mapping.data_ptr(), t, 0 if skip_query else hq, hkv, head_size,
+            cos_sin_cache.shape[1], q2.stride(0),
             k2.stride(0), v2.stride(0), key_cache.size(3), key_cache.size(4),
             1 if is_neox else 0, _dt(query), _lib.kv_dtype_code(kv_cache_dtype), kv_scale, sp, ns,
             sstride, srow, 0, hq * head_size, (hq + hkv) * head_size, _stream(query.device)),
             "rotary_reshape_and_cache")
+
+
+def rope_paged_attention_supported(num_heads: int, num_kv_heads: int, head_size: int, rot_dim: int,
+                                   is_neox: bool, block_size: int, dtype: torch.dtype) -> bool:
+    """Whether rope_paged_attention takes a decode step of this shape."""
+    if dtype not in _DTYPE:
+        return False
+    return bool(_lib.lib().vla_rope_paged_attention_supported(
+        num_heads, num_kv_heads, head_size, rot_dim, 1 if is_neox else 0, block_size, _DTYPE[dtype]))
+
+
+def rope_paged_attention(positions: torch.Tensor, query: torch.Tensor, key: torch.Tensor,
+                         value: torch.Tensor, head_size: int, cos_sin_cache: torch.Tensor,
+                         is_neox: bool, key_cache, value_cache, slot_mapping: torch.Tensor,
+                         kv_cache_dtype: str, kv_scale: float, num_kv_heads: int, scale: float,
+                         block_tables: torch.Tensor, seq_lens: torch.Tensor, max_seq_len: int,
+                         alibi_slopes: Optional[torch.Tensor] = None,
+                         slabs: Optional[SplitKSlabs] = None,
+                         seq_order: Optional[torch.Tensor] = None,
+                         use_v1: bool = True, write_kv: bool = True) -> torch.Tensor:
+    """rotary_reshape_and_cache followed by paged_attention_v1 / _v2 of a decode step (token t is
+    sequence t) in one launch: same cache bytes, same output.  query [T, Hq*D], key / value
+    [T, Hkv*D] hold the UNROTATED rows (strided row views of one qkv tensor are fine) and are left
+    as they are; with `slabs` (the unreduced qkv projection, columns q | k | v) they are not read.
+    write_kv=False: key and value of the step are in the cache already (rotary_reshape_and_cache
+    with an empty query puts them there); only the query's rotation rides in the launch.
+    Returns [T, Hq*D]."""
+    _require_cuda(positions, query, key, value, cos_sin_cache, slot_mapping, block_tables, seq_lens,
+                  alibi_slopes, seq_order)
+    assert positions.dtype == torch.int64 and positions.is_contiguous()
+    assert slot_mapping.dtype == torch.int64 and slot_mapping.is_contiguous()
+    assert cos_sin_cache.dtype == query.dtype and cos_sin_cache.is_contiguous()
+    assert block_tables.dtype == torch.int32 and seq_lens.dtype == torch.int32
+    assert block_tables.stride(1) == 1
+    t = positions.numel()
+    q2, k2, v2 = query.view(t, -1), key.view(t, -1), value.view(t, -1)
+    assert q2.stride(1) == 1 and k2.stride(1) == 1 and v2.stride(1) == 1
+    hq, hkv = q2.shape[1] // head_size, k2.shape[1] // head_size
+    assert hkv == num_kv_heads
+    _check_seq_order(seq_order, t)
+    sp, ns, sstride, srow = None, 0, 0, 0
+    if slabs is not None:
+        assert slabs.m == t and slabs.n == (hq + 2 * hkv) * head_size
+        sp, ns, sstride, srow = slabs.workspace.data_ptr(), slabs.num_slabs, slabs.m * slabs.n, slabs.n
+    out = torch.empty((t, hq * head_size), dtype=query.dtype, device=query.device)
+    block_size = value_cache.shape[3]
+    es = ml = tmp = None
+    if not use_v1:
+        parts = (max_seq_len + 511) // 512
+        tmp = torch.empty((t, hq, parts, head_size), dtype=query.dtype, device=query.device)
+        es = torch.empty((t, hq, parts), dtype=torch.float32, device=query.device)
+        ml = torch.empty_like(es)
+    with torch.cuda.device(query.device):
+        check(_lib.lib().vla_rope_paged_attention(
+            out.data_ptr(), _ptr(es), _ptr(ml), _ptr(tmp), q2.data_ptr(), k2.data_ptr(),
+            v2.data_ptr(), q2.stride(0), k2.stride(0), v2.stride(0), positions.data_ptr(),
+            cos_sin_cache.data_ptr(), cos_sin_cache.shape[1], 1 if is_neox else 0,
+            key_cache.data_ptr(), value_cache.data_ptr(), slot_mapping.data_ptr(), sp, ns, sstride,
+            srow, 0, hq * head_size, (hq + hkv) * head_size, t, hq, hkv, head_size, block_size,
+            scale, block_tables.data_ptr(), seq_lens.data_ptr(), block_tables.stride(0),
+            max_seq_len, _ptr(alibi_slopes), key_cache.stride(0), key_cache.stride(1), _dt(query),
+            _lib.kv_dtype_code(kv_cache_dtype), kv_scale, _ptr(seq_order), 1 if write_kv else 0,
+            _stream(query.device)), "rope_paged_attention")
+    return out
 
 
 def fused_add_rms_norm_splitk(slabs: SplitKSlabs, out: torch.Tensor, residual: torch.Tensor,

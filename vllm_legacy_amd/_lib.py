@@ -37,7 +37,7 @@ EXPORTS = [
     "vla_ar_free_region", "vla_ar_export", "vla_ar_import", "vla_ar_unimport", "vla_ar_create", "vla_ar_destroy",
     "vla_ar_all_reduce", "vla_ar_all_reduce_slabs", "vla_ar_all_reduce_add_rms_norm", "vla_ar_error_count", "vla_ar_error_count_async", "vla_q4_gemm_grouped", "vla_q4_gemm_grouped_workspace_bytes",
     "vla_q4_gemm_grouped_gather", "vla_moe_route_topk", "vla_moe_gate_topk", "vla_moe_sort_pairs", "vla_moe_combine", "vla_moe_gather_perm",
-    "vla_q4_gemm_packed_partial", "vla_q4_gemm_silu_and_mul_supported", "vla_q4_gemm_packed_silu_and_mul", "vla_rotary_reshape_and_cache", "vla_fused_add_rms_norm_splitk", "vla_silu_and_mul_splitk",
+    "vla_q4_gemm_packed_partial", "vla_q4_gemm_silu_and_mul_supported", "vla_q4_gemm_packed_silu_and_mul", "vla_rotary_reshape_and_cache", "vla_rope_paged_attention_supported", "vla_rope_paged_attention", "vla_fused_add_rms_norm_splitk", "vla_silu_and_mul_splitk",
 ]
 
 
@@ -176,6 +176,10 @@ def lib():
         L.vla_rotary_reshape_and_cache.argtypes = [p, p, p, p, p, p, p, p, i, i, i, i, i, i64, i64,
                                                    i64, i, i, i, i, i, f, p, i, i64, i64, i, i, i,
                                                    p]
+        L.vla_rope_paged_attention_supported.argtypes = [i, i, i, i, i, i, i]
+        L.vla_rope_paged_attention.argtypes = [p, p, p, p, p, p, p, i64, i64, i64, p, p, i, i, p, p,
+                                               p, p, i, i64, i64, i, i, i, i, i, i, i, i, f, p, p,
+                                               i, i, p, i64, i64, i, i, f, p, i, p]
         L.vla_fused_add_rms_norm_splitk.argtypes = [p, i, i64, p, p, p, f, i, i, i, p]
         L.vla_silu_and_mul_splitk.argtypes = [p, i, i64, p, i, i, i, p]
         _lib = L

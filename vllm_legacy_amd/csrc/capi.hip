@@ -69,8 +69,9 @@ static int kv_nontemporal(int num_seqs, int max_tokens, int num_kv_heads, int he
 extern "C" int vla_abi_version(void) { return 1; }
 
 // Which kernel a paged-attention call of this shape runs on, spelled the way a profiler prints the
-// instantiation ("pa_mfma_kernel<vla::F16, true, 128, 16, false, true>": model dtype, fp8 cache,
-// head size, block size, partitioned (V2), nontemporal K/V loads), or "pa_generic_kernel" for
+// instantiation ("pa_mfma_kernel<vla::F16, true, 128, 16, false, true, false>": model dtype, fp8
+// cache, head size, block size, partitioned (V2), nontemporal K/V loads, rotary + cache write fused
+// in (vla_rope_paged_attention only)), or "pa_generic_kernel" for
 // shapes the MFMA kernel does not take.  Assumes 16-byte aligned caches and strides.
 extern "C" int vla_paged_attention_kernel_name(char* buf, int buf_len, int num_seqs, int num_kv_heads,
                                                int head_size, int block_size, int max_seq_len,
@@ -86,7 +87,7 @@ extern "C" int vla_paged_attention_kernel_name(char* buf, int buf_len, int num_s
     return VLA_OK;
   }
   const int nt = kv_nontemporal(num_seqs, max_seq_len, num_kv_heads, head_size, kv_dtype);
-  snprintf(buf, buf_len, "pa_mfma_kernel<vla::%s, %s, %d, %d, %s, %s>", dtype == VLA_F16 ? "F16" : "BF16",
+  snprintf(buf, buf_len, "pa_mfma_kernel<vla::%s, %s, %d, %d, %s, %s, false>", dtype == VLA_F16 ? "F16" : "BF16",
            kv_dtype == VLA_KV_FP8_E4M3 ? "true" : "false", head_size, block_size,
            partitioned ? "true" : "false", nt ? "true" : "false");
   return VLA_OK;
@@ -232,6 +233,69 @@ extern "C" int vla_paged_attention_v2(
       max_seq_len, alibi_slopes, q_stride, kv_block_stride, kv_head_stride, dtype, kv_dtype,
       kv_scale, tp_rank, blocksparse_local_blocks, blocksparse_vert_stride, blocksparse_block_size,
       blocksparse_head_sliding_step, nullptr, stream);
+}
+
+// ---- rotary embedding + cache write + paged attention of a decode step in one launch -----------
+// What vla_rotary_reshape_and_cache followed by vla_paged_attention_v1 / _v2 computes (same
+// arithmetic, same bits in the cache and in `out`), for the shapes paged_attention_rope_fusable
+// names; the rotated query and key are not written back to their tensors.  write_kv == 0: the
+// step's key and value are in the cache already (vla_rotary_reshape_and_cache with num_heads 0
+// puts them there) and only the query's rotation rides in the attention launch.  exp_sums / max_logits /
+// tmp_out null: V1.  Returns VLA_ERR_ARG for a shape or layout the fused kernel does not take.
+extern "C" int vla_rope_paged_attention_supported(int num_heads, int num_kv_heads, int head_size,
+                                                  int rot_dim, int is_neox, int block_size,
+                                                  int dtype) {
+  return (g_attention_path.load(std::memory_order_relaxed) == 0 && is_neox && rot_dim == head_size &&
+          paged_attention_rope_fusable(num_heads, num_kv_heads, head_size, block_size, dtype)) ? 1 : 0;
+}
+
+extern "C" int vla_rope_paged_attention(
+    void* out, float* exp_sums, float* max_logits, void* tmp_out, const void* query,
+    const void* key, const void* value, int64_t q_stride, int64_t k_stride, int64_t v_stride,
+    const int64_t* positions, const void* cos_sin_cache, int rot_dim, int is_neox, void* key_cache,
+    void* value_cache, const int64_t* slot_mapping, const float* slabs, int num_slabs,
+    int64_t slab_stride, int64_t slab_row, int q_col, int k_col, int v_col, int num_seqs,
+    int num_heads, int num_kv_heads, int head_size, int block_size, float scale,
+    const int* block_tables, const int* seq_lens, int max_num_blocks_per_seq, int max_seq_len,
+    const float* alibi_slopes, int64_t kv_block_stride, int64_t kv_head_stride, int dtype,
+    int kv_dtype, float kv_scale, const int* seq_order, int write_kv, void* stream) {
+  (void)hipGetLastError();
+  int rc = check_attn(out, slabs ? (const void*)slabs : query, key_cache, value_cache, num_seqs,
+                      num_heads, num_kv_heads, head_size, block_size, block_tables, seq_lens,
+                      max_num_blocks_per_seq, dtype, kv_dtype, 0);
+  if (rc != VLA_OK) return rc;
+  if (!positions || !cos_sin_cache || !slot_mapping || max_seq_len <= 0) return VLA_ERR_ARG;
+  if (!slabs && (!query || (write_kv && (!key || !value)))) return VLA_ERR_ARG;
+  if (!vla_rope_paged_attention_supported(num_heads, num_kv_heads, head_size, rot_dim, is_neox,
+                                          block_size, dtype))
+    return VLA_ERR_ARG;
+  const bool v2 = exp_sums || max_logits || tmp_out;
+  if (v2 && (!exp_sums || !max_logits || !tmp_out)) return VLA_ERR_ARG;
+  if (num_seqs == 0) return VLA_OK;
+  const int P = v2 ? (max_seq_len + VLA_PARTITION_SIZE - 1) / VLA_PARTITION_SIZE : 0;
+  AttnParams p{};
+  p.out = v2 ? tmp_out : out; p.exp_sums = exp_sums; p.max_logits = max_logits;
+  p.q = query; p.k_cache = key_cache; p.v_cache = value_cache;
+  p.block_tables = block_tables; p.seq_lens = seq_lens; p.alibi_slopes = alibi_slopes;
+  p.num_seqs = num_seqs; p.num_heads = num_heads; p.num_kv_heads = num_kv_heads;
+  p.head_size = head_size; p.block_size = block_size;
+  p.max_num_blocks_per_seq = max_num_blocks_per_seq; p.max_num_partitions = P;
+  p.scale = scale; p.kv_scale = kv_scale;
+  p.q_stride = q_stride; p.kv_block_stride = kv_block_stride; p.kv_head_stride = kv_head_stride;
+  p.seq_order = seq_order;
+  p.kv_nontemporal = kv_nontemporal(num_seqs, max_seq_len, num_kv_heads, head_size, kv_dtype);
+  RopeFuse rf{};
+  rf.positions = positions; rf.slots = slot_mapping; rf.cos_sin = cos_sin_cache;
+  rf.k = key; rf.v = value; rf.k_stride = k_stride; rf.v_stride = v_stride;
+  rf.slabs = slabs; rf.num_slabs = num_slabs; rf.slab_stride = slab_stride; rf.slab_row = slab_row;
+  rf.q_col = q_col; rf.k_col = k_col; rf.v_col = v_col;
+  rf.write_kv = write_kv ? 1 : 0;
+  hipStream_t s = (hipStream_t)stream;
+  rc = launch_paged_attention_mfma(p, dtype, kv_dtype, s, &rf);
+  if (rc < 0) return VLA_ERR_ARG;
+  if (rc != VLA_OK || !v2) return rc;
+  return launch_paged_attention_v2_reduce(out, exp_sums, max_logits, tmp_out, seq_lens, num_seqs,
+                                          num_heads, head_size, P, dtype, s);
 }
 
 // ---- paged_attention_v2 for callers that cannot allocate ---------------------------------------

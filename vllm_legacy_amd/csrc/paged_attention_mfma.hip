@@ -97,6 +97,43 @@ __device__ __forceinline__ u32x4 cvt8(uint32_t w0, uint32_t w1) {
   return r;
 }
 
+template <class S>
+__device__ __forceinline__ float pa_rnd(float v) { return S::to_f32(S::from_f32(v)); }
+
+// NeoX rotation of one (x, y) = (dim d, dim d + D/2) pair with the rounding steps of the rotary
+// kernel (csrc/pos_encoding_kernels.cu:10-36 in the model dtype: every product and the sum rounded)
+template <class S>
+__device__ __forceinline__ void rope_pair(float x, float y, float c, float s, float& xr, float& yr) {
+#pragma clang fp contract(off)
+  xr = pa_rnd<S>(pa_rnd<S>(x * c) - pa_rnd<S>(y * s));
+  yr = pa_rnd<S>(pa_rnd<S>(y * c) + pa_rnd<S>(x * s));
+}
+
+// eight consecutive elements of a token's row as the model dtype would hold them: from the tensor,
+// or from the split-K slabs (summed in slab order, then rounded)
+template <class S>
+__device__ __forceinline__ void row8(const typename S::T* t, const float* srow, int num_slabs,
+                                     int64_t slab_stride, int col, float (&f)[8]) {
+  if (srow) {
+    f32x4 a = *reinterpret_cast<const f32x4*>(srow + col);
+    f32x4 b = *reinterpret_cast<const f32x4*>(srow + col + 4);
+    for (int p = 1; p < num_slabs; ++p) {
+      a += *reinterpret_cast<const f32x4*>(srow + (int64_t)p * slab_stride + col);
+      b += *reinterpret_cast<const f32x4*>(srow + (int64_t)p * slab_stride + col + 4);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      f[e] = pa_rnd<S>(a[e]);
+      f[4 + e] = pa_rnd<S>(b[e]);
+    }
+  } else {
+    const u32x4 w = *reinterpret_cast<const u32x4*>(t);
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+      f[e] = S::to_f32(__builtin_bit_cast(typename S::T, (uint16_t)(w[e >> 1] >> (16 * (e & 1)))));
+  }
+}
+
 // keep the first `nvalid` tokens of a 16-byte V load, zero the rest (they may hold NaNs,
 // attention_kernels.cu:420-430)
 template <bool FP8>
@@ -120,8 +157,22 @@ __device__ __forceinline__ u32x4 mask_tokens(u32x4 v, int nvalid) {
 // two 8-byte loads from two blocks; a 16-bit V row is exactly one 16-byte load.
 // KVNT: nontemporal K / V loads (a template parameter: behind a run-time branch the compiler
 // merges the two otherwise identical load groups and drops the hint)
-template <class S, bool FP8, int D, int BS, bool PARTITIONED, bool KVNT>
-__global__ __launch_bounds__(kThreads, 2) void pa_mfma_kernel(AttnParams p, int heads_per_wg) {
+// FUSE: the launch also rotates this step's query and, with RopeFuse::write_kv, rotates the key
+// and writes key and value into the cache (see RopeFuse; D == 128, the whole GQA group in one
+// workgroup).  After the first K requests have gone out the workgroup rotates its heads' query
+// once, a rotation pair per thread, into LDS, from where every wave takes its fragments: measured
+// free (batch 256 x 4096 tokens, fp8 cache: 345 us against 360 for the rotary launch + the plain
+// kernel).  The new token belongs to the LAST step of its sequence, which one wave owns: with
+// write_kv that wave rotates the key, stores key and value into the cache and waits for the
+// stores' acknowledgement once, before its K loop.  No other wave, and no other workgroup, reads
+// those bytes in this launch (a step covers whole blocks, and a (block, KV head) region belongs to
+// one workgroup).  The K loop is the unfused one, untouched.  The cache write is NOT free once the
+// launch saturates HBM: 2048 workgroups' scattered byte stores inside the read stream cost 30 us
+// at that size (375 us), more than the launch they save, so large batches keep the cache write in
+// its own launch (key and value only) and small ones (a few sequences) take everything here.
+template <class S, bool FP8, int D, int BS, bool PARTITIONED, bool KVNT, bool FUSE = false>
+__global__ __launch_bounds__(kThreads, 2) void pa_mfma_kernel(AttnParams p, int heads_per_wg,
+                                                              RopeFuse rf, int q_lds_off) {
   using T = typename S::T;
   constexpr int kBS = BS;
   constexpr int X = FP8 ? 16 : 8;          // elements per 16-byte K chunk
@@ -169,7 +220,7 @@ __global__ __launch_bounds__(kThreads, 2) void pa_mfma_kernel(AttnParams p, int 
 
   // ---- query fragments (B operand of q.K), zero rows for heads this workgroup does not own
   u32x4 qf[KS];
-  {
+  if constexpr (!FUSE) {
     const T* q = reinterpret_cast<const T*>(p.q) + (int64_t)seq * p.q_stride +
                  (int64_t)(head_base + c) * D;
 #pragma unroll
@@ -226,11 +277,101 @@ __global__ __launch_bounds__(kThreads, 2) void pa_mfma_kernel(AttnParams p, int 
     }
   };
 
+  // ---- FUSE: the owner of the last step puts the new token's key and value into the cache
+  bool kv_writer = false;
+  if constexpr (FUSE)
+    kv_writer = rf.write_kv && tok_end == seq_len && wave == (nsteps - 1) % kWaves &&
+                rf.slots[seq] >= 0;
+  auto write_new_kv = [&]() {
+    if constexpr (FUSE) {
+      const int64_t slot = rf.slots[seq];
+      const int64_t blk = slot / kBS;
+      const int off = (int)(slot - blk * kBS);
+      const T* cs = reinterpret_cast<const T*>(rf.cos_sin) + rf.positions[seq] * D;
+      const float* srow = rf.slabs ? rf.slabs + (int64_t)seq * rf.slab_row : nullptr;
+      auto elem = [&](const void* t, int64_t stride, int col, int d) -> float {
+        if (srow) {
+          float a = srow[col + kv_head * D + d];
+          for (int q = 1; q < rf.num_slabs; ++q)
+            a += srow[(int64_t)q * rf.slab_stride + col + kv_head * D + d];
+          return pa_rnd<S>(a);
+        }
+        return S::to_f32(reinterpret_cast<const T*>(t)[(int64_t)seq * stride + kv_head * D + d]);
+      };
+      unsigned char* kdst = const_cast<unsigned char*>(kbase) + blk * blk_bytes;
+      unsigned char* vdst = const_cast<unsigned char*>(vbase) + blk * blk_bytes;
+      auto put_k = [&](int d, float val) {
+        unsigned char* a = kdst + ((d / X) * kBS + off) * 16 + (d % X) * CE;
+        if constexpr (FP8) *a = fp8_e4m3_encode(val / p.kv_scale);
+        else *reinterpret_cast<T*>(a) = S::from_f32(val);
+      };
+      auto put_v = [&](int d, float val) {
+        unsigned char* a = vdst + (d * kBS + off) * CE;
+        if constexpr (FP8) *a = fp8_e4m3_encode(val / p.kv_scale);
+        else *reinterpret_cast<T*>(a) = S::from_f32(val);
+      };
+      // lane l: rotation pair (l, l + 64) of the key, dims l and l + 64 of the value
+      float xr, yr;
+      rope_pair<S>(elem(rf.k, rf.k_stride, rf.k_col, lane), elem(rf.k, rf.k_stride, rf.k_col, lane + 64),
+                   S::to_f32(cs[lane]), S::to_f32(cs[64 + lane]), xr, yr);
+      put_k(lane, xr);
+      put_k(lane + 64, yr);
+      put_v(lane, elem(rf.v, rf.v_stride, rf.v_col, lane));
+      put_v(lane + 64, elem(rf.v, rf.v_stride, rf.v_col, lane + 64));
+    }
+  };
+  // The first K requests go out BEFORE the rotation work, which then runs while they are in
+  // flight -- except in the wave whose first step is already the one that holds the new token.
+  const bool kv_first = FUSE && kv_writer && wave == nsteps - 1;
+  if (kv_first) {
+    write_new_kv();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the stores have reached memory
+  }
   int cur_blk[NB];
   u32x4 kb[NT * KL];
   if (wave < nsteps) {
     step_blocks(wave, cur_blk);
     load_k(cur_blk, kb);
+  }
+  if constexpr (FUSE) {
+    // ---- the rotated query of the workgroup's heads: one rotation pair per thread into LDS, from
+    // where every wave takes its fragments; and, in the owner of the last step, the cache write
+    static_assert(D == 128, "whole-head NeoX rotation of a 128-dim head");
+    constexpr int Q_PITCH = D * 2 + 16;          // bytes per head row
+    unsigned char* q_lds = smem + q_lds_off;
+    {
+      const T* cs = reinterpret_cast<const T*>(rf.cos_sin) + rf.positions[seq] * D;
+      const float* srow = rf.slabs ? rf.slabs + (int64_t)seq * rf.slab_row : nullptr;
+      const T* q = reinterpret_cast<const T*>(p.q) + (int64_t)seq * p.q_stride + (int64_t)head_base * D;
+      auto elem = [&](int i) -> float {          // element i of the workgroup's heads, unrotated
+        if (srow) {
+          const int col = rf.q_col + head_base * D + i;
+          float a = srow[col];
+          for (int t = 1; t < rf.num_slabs; ++t) a += srow[(int64_t)t * rf.slab_stride + col];
+          return pa_rnd<S>(a);
+        }
+        return S::to_f32(q[i]);
+      };
+      for (int idx = threadIdx.x; idx < nheads * (D / 2); idx += kThreads) {
+        const int h = idx / (D / 2), o = idx - h * (D / 2);
+        float xr, yr;
+        rope_pair<S>(elem(h * D + o), elem(h * D + D / 2 + o), S::to_f32(cs[o]),
+                     S::to_f32(cs[D / 2 + o]), xr, yr);
+        *reinterpret_cast<T*>(q_lds + h * Q_PITCH + o * 2) = S::from_f32(xr);
+        *reinterpret_cast<T*>(q_lds + h * Q_PITCH + (D / 2 + o) * 2) = S::from_f32(yr);
+      }
+    }
+    if (kv_writer && !kv_first) write_new_kv();
+    __syncthreads();
+    // the writer's stores have reached memory before it requests anything else: the step that
+    // reads them back is one of its own, later ones
+    if (kv_writer) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int d0 = FP8 ? 16 * (g + 4 * (ks >> 1)) + 8 * (ks & 1) : 8 * (g + 4 * ks);
+      qf[ks] = c < nheads ? *reinterpret_cast<const u32x4*>(q_lds + c * Q_PITCH + d0 * 2)
+                          : u32x4{0, 0, 0, 0};
+    }
   }
 
   for (int step = wave; step < nsteps; step += kWaves) {
@@ -418,7 +559,7 @@ __global__ __launch_bounds__(kThreads, 2) void pa_mfma_kernel(AttnParams p, int 
 }
 
 template <class S, bool FP8, int D, int BS>
-int launch_b(const AttnParams& p, hipStream_t s) {
+int launch_b(const AttnParams& p, hipStream_t s, const RopeFuse* fuse) {
   const int qpk = p.num_heads / p.num_kv_heads;
   // query heads per workgroup: the whole GQA group when it fits the 16 rows of a tile
   int hpw = qpk <= 16 ? qpk : 16;
@@ -427,57 +568,90 @@ int launch_b(const AttnParams& p, hipStream_t s) {
   const size_t p_bytes = (size_t)kWaves * 16 * (STEP * 2 + 16);
   const size_t merge_bytes = (size_t)kWaves * 32 * 4 + (size_t)kWaves * hpw * D * 4;
   const size_t smem = p_bytes > merge_bytes ? p_bytes : merge_bytes;
-  if (smem > 64 * 1024) return -1;  // beyond the default dynamic-LDS limit: generic kernel
+  const size_t q_bytes = (size_t)hpw * (D * 2 + 16);   // FUSE: the rotated query of the workgroup
+  if (smem + q_bytes > 64 * 1024) return -1;  // beyond the default dynamic-LDS limit: generic kernel
   dim3 grid(p.num_kv_heads * groups_per_kv, p.num_seqs,
             p.max_num_partitions > 0 ? p.max_num_partitions : 1);
-  if (p.max_num_partitions > 0) {
-    if (p.kv_nontemporal)
-      hipLaunchKernelGGL((pa_mfma_kernel<S, FP8, D, BS, true, true>), grid, dim3(kThreads), smem, s, p, hpw);
-    else
-      hipLaunchKernelGGL((pa_mfma_kernel<S, FP8, D, BS, true, false>), grid, dim3(kThreads), smem, s, p, hpw);
-  } else {
-    if (p.kv_nontemporal)
-      hipLaunchKernelGGL((pa_mfma_kernel<S, FP8, D, BS, false, true>), grid, dim3(kThreads), smem, s, p, hpw);
-    else
-      hipLaunchKernelGGL((pa_mfma_kernel<S, FP8, D, BS, false, false>), grid, dim3(kThreads), smem, s, p, hpw);
+#define VLA_PA_LAUNCH(PART, NTL, FUSED)                                                          \
+  hipLaunchKernelGGL((pa_mfma_kernel<S, FP8, D, BS, PART, NTL, FUSED>), grid, dim3(kThreads),   \
+                     smem + (FUSED ? q_bytes : 0), s, p, hpw, rf, (int)smem)
+#define VLA_PA_NT(PART, FUSED)                                                                   \
+  do {                                                                                           \
+    if (p.kv_nontemporal) VLA_PA_LAUNCH(PART, true, FUSED); else VLA_PA_LAUNCH(PART, false, FUSED); \
+  } while (0)
+  const RopeFuse rf = fuse ? *fuse : RopeFuse{};
+  if constexpr (D == 128) {
+    if (fuse) {
+      if (groups_per_kv != 1) return -1;
+      if (p.max_num_partitions > 0) VLA_PA_NT(true, true); else VLA_PA_NT(false, true);
+      VLA_HIP_CHECK(hipGetLastError());
+      return VLA_OK;
+    }
   }
+  if (fuse) return -1;
+  if (p.max_num_partitions > 0) VLA_PA_NT(true, false); else VLA_PA_NT(false, false);
+#undef VLA_PA_NT
+#undef VLA_PA_LAUNCH
   VLA_HIP_CHECK(hipGetLastError());
   return VLA_OK;
 }
 
 template <class S, bool FP8, int D>
-int launch_t(const AttnParams& p, hipStream_t s) {
-  return p.block_size == 16 ? launch_b<S, FP8, D, 16>(p, s)
-         : p.block_size == 32 ? launch_b<S, FP8, D, 32>(p, s) : launch_b<S, FP8, D, 8>(p, s);
+int launch_t(const AttnParams& p, hipStream_t s, const RopeFuse* fuse) {
+  return p.block_size == 16 ? launch_b<S, FP8, D, 16>(p, s, fuse)
+         : p.block_size == 32 ? launch_b<S, FP8, D, 32>(p, s, fuse) : launch_b<S, FP8, D, 8>(p, s, fuse);
 }
 
 template <class S, bool FP8>
-int launch_d(const AttnParams& p, hipStream_t s) {
+int launch_d(const AttnParams& p, hipStream_t s, const RopeFuse* fuse) {
   switch (p.head_size) {
-    case 64: return launch_t<S, FP8, 64>(p, s);
-    case 80: return launch_t<S, FP8, 80>(p, s);
-    case 96: return launch_t<S, FP8, 96>(p, s);
-    case 112: return launch_t<S, FP8, 112>(p, s);
-    case 128: return launch_t<S, FP8, 128>(p, s);
-    case 192: return launch_t<S, FP8, 192>(p, s);
-    case 256: return launch_t<S, FP8, 256>(p, s);
+    case 64: return launch_t<S, FP8, 64>(p, s, fuse);
+    case 80: return launch_t<S, FP8, 80>(p, s, fuse);
+    case 96: return launch_t<S, FP8, 96>(p, s, fuse);
+    case 112: return launch_t<S, FP8, 112>(p, s, fuse);
+    case 128: return launch_t<S, FP8, 128>(p, s, fuse);
+    case 192: return launch_t<S, FP8, 192>(p, s, fuse);
+    case 256: return launch_t<S, FP8, 256>(p, s, fuse);
     default: return -1;
   }
 }
 
 }  // namespace
 
-int launch_paged_attention_mfma(const AttnParams& p, int dtype, int kv_dtype, hipStream_t s) {
+bool paged_attention_rope_fusable(int num_heads, int num_kv_heads, int head_size, int block_size,
+                                  int dtype) {
+  if (num_heads <= 0 || num_kv_heads <= 0 || num_heads % num_kv_heads) return false;
+  return head_size == 128 && num_heads / num_kv_heads <= 16 &&
+         (block_size == 8 || block_size == 16 || block_size == 32) &&
+         (dtype == VLA_F16 || dtype == VLA_BF16);
+}
+
+int launch_paged_attention_mfma(const AttnParams& p, int dtype, int kv_dtype, hipStream_t s,
+                                const RopeFuse* fuse) {
   if (p.block_size != 8 && p.block_size != 16 && p.block_size != 32) return -1;
   if (dtype != VLA_F16 && dtype != VLA_BF16) return -1;
   const bool fp8 = kv_dtype == VLA_KV_FP8_E4M3;
   const int ce = fp8 ? 1 : 2;
   // 16-byte loads: aligned bases and strides, 16-byte aligned query rows
-  if (((uintptr_t)p.k_cache | (uintptr_t)p.v_cache | (uintptr_t)p.q) % 16) return -1;
-  if ((p.kv_block_stride * ce) % 16 || (p.kv_head_stride * ce) % 16 || (p.q_stride * 2) % 16)
+  if (((uintptr_t)p.k_cache | (uintptr_t)p.v_cache) % 16) return -1;
+  if ((p.kv_block_stride * ce) % 16 || (p.kv_head_stride * ce) % 16) return -1;
+  if (fuse) {
+    if (!paged_attention_rope_fusable(p.num_heads, p.num_kv_heads, p.head_size, p.block_size, dtype))
+      return -1;
+    if ((uintptr_t)fuse->cos_sin % 16) return -1;
+    if (fuse->slabs) {
+      if (((uintptr_t)fuse->slabs % 16) || fuse->slab_stride % 4 || fuse->slab_row % 4 ||
+          fuse->q_col % 4 || fuse->k_col % 4 || fuse->v_col % 4 || fuse->num_slabs < 1)
+        return -1;
+    } else if (((uintptr_t)p.q % 16) || (p.q_stride * 2) % 16 || (fuse->write_kv && (!fuse->k || !fuse->v))) {
+      return -1;
+    }
+  } else if (((uintptr_t)p.q % 16) || (p.q_stride * 2) % 16) {
     return -1;
-  if (dtype == VLA_F16) return fp8 ? launch_d<F16, true>(p, s) : launch_d<F16, false>(p, s);
-  return fp8 ? launch_d<BF16, true>(p, s) : launch_d<BF16, false>(p, s);
+  }
+  if (dtype == VLA_F16)
+    return fp8 ? launch_d<F16, true>(p, s, fuse) : launch_d<F16, false>(p, s, fuse);
+  return fp8 ? launch_d<BF16, true>(p, s, fuse) : launch_d<BF16, false>(p, s, fuse);
 }
 
 }  // namespace vla

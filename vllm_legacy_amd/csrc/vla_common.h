@@ -144,7 +144,29 @@ struct AttnParams {
 // implemented in paged_attention_generic.hip / paged_attention_mfma.hip
 int launch_paged_attention_generic(const AttnParams& p, int dtype, int kv_dtype, hipStream_t s);
 // returns -1 when the shape is not covered by the MFMA path (caller falls back to generic)
-int launch_paged_attention_mfma(const AttnParams& p, int dtype, int kv_dtype, hipStream_t s);
+// Rotary embedding of this step's query and key and (write_kv) the cache write of the rotated key
+// and of the value, done inside the paged-attention launch (paged_attention_mfma.hip, FUSE instantiations):
+// token t of the step is sequence t.  AttnParams::q then holds the UNROTATED query (ignored when
+// `slabs` is set: q, k, v are columns q_col / k_col / v_col of the fp32 split-K slabs
+// [num_slabs][tokens][slab_row] of the qkv projection, summed in slab order and rounded to the
+// model dtype first).
+struct RopeFuse {
+  const int64_t* positions;   // [tokens]
+  const int64_t* slots;       // [tokens], < 0: the token is not cached
+  const void* cos_sin;        // [max_position][head_size] model dtype: cos | sin (NeoX, whole head)
+  const void* k;              // [tokens, k_stride] model dtype (no slabs)
+  const void* v;
+  int64_t k_stride, v_stride;
+  const float* slabs;
+  int num_slabs;
+  int64_t slab_stride, slab_row;
+  int q_col, k_col, v_col;
+  int write_kv;               // 0: the key / value of the step are in the cache already; only the query is rotated here
+};
+bool paged_attention_rope_fusable(int num_heads, int num_kv_heads, int head_size, int block_size,
+                                  int dtype);
+int launch_paged_attention_mfma(const AttnParams& p, int dtype, int kv_dtype, hipStream_t s,
+                                const RopeFuse* fuse = nullptr);
 int launch_paged_attention_v2_reduce(void* out, const float* exp_sums, const float* max_logits,
                                      const void* tmp_out, const int* seq_lens, int num_seqs,
                                      int num_heads, int head_size, int max_num_partitions,

@@ -10,10 +10,9 @@ lookup and the fp16 lm_head are plain PyTorch-ROCm ops.
 Weights are random (no checkpoints are available offline); this module exists to drive the
 decode-step benchmark and the tensor-parallel tests, not to load models.
 """
+import os
 from dataclasses import dataclass
 from typing import List, Optional
-
-import os
 
 import torch
 import torch.nn as nn
@@ -31,6 +30,11 @@ from vllm_legacy_amd.distributed.parallel_state import (get_tensor_model_paralle
 from vllm_legacy_amd.layers import RMSNorm, RotaryEmbedding, SiluAndMul
 from vllm_legacy_amd.quantization.awq import AWQConfig, AWQLinearMethod
 from vllm_legacy_amd.quantization.gptq import GPTQConfig, GPTQLinearMethod
+
+
+# (sequences x KV heads) below which rotary embedding and the cache write of a decode step ride in
+# its attention launch
+_ROPE_ATTN_BELOW = int(os.environ.get("VLA_ROPE_ATTN_BELOW", "320"))
 
 
 @dataclass
@@ -178,6 +182,26 @@ class LlamaDecodeLayer(nn.Module):
         self.attn = Attention(self.hq, d, d**-0.5, self.hkv, kv_cache_dtype=kv_cache_dtype,
                               dtype=dtype)
 
+    def _rope_in_attention(self, rotary_emb, block_size: int, dtype, num_seqs: int) -> bool:
+        """Whether a decode step of this layer takes the launch that does rotary embedding, cache
+        write and paged attention at once: batches of a few sequences, where it saves one of the
+        layer's launches (Llama-3-8B stack from a graph: batch 1 2.30 -> 2.20 ms per step, batch 8
+        2.61 -> 2.49, batch 32 4.11 -> 4.00).  Once the attention launch saturates HBM the cache
+        write's scattered stores inside its read stream cost more than the launch they save
+        (batch 256: 375 against 363 us per layer), and with the write in a launch of its own the
+        query's rotation alone is worth nothing (16.55-16.74 against 16.71-16.76 ms per step).
+        VLA_FUSE_ROPE_ATTN=0 keeps the separate launches everywhere."""
+        if os.environ.get("VLA_FUSE_ROPE_ATTN", "1") == "0":
+            return False
+        if num_seqs * self.hkv >= _ROPE_ATTN_BELOW:
+            return False
+        impl = self.attn.impl
+        if getattr(impl, "blocksparse", None) is not None or getattr(impl, "alibi_slopes", None) is not None:
+            return False
+        return ops.rope_paged_attention_supported(self.hq, self.hkv, self.cfg.head_dim,
+                                                  rotary_emb.cos_sin_cache.shape[1],
+                                                  rotary_emb.is_neox_style, block_size, dtype)
+
     def forward(self, positions, hidden, residual, kv_cache, attn_metadata, rotary_emb):
         """Layer order of vllm/model_executor/models/llama.py:196-224.  `hidden` may arrive as the
         previous layer's unreduced down projection (ops.SplitKSlabs); fused kernels are used
@@ -197,11 +221,22 @@ class LlamaDecodeLayer(nn.Module):
         if decode_only:
             key_cache, value_cache = PagedAttention.split_kv_cache(kv_cache, self.hkv,
                                                                    self.cfg.head_dim)
-            ops.rotary_reshape_and_cache(positions, q, k, v, self.cfg.head_dim,
-                                         rotary_emb.cos_sin_cache, rotary_emb.is_neox_style,
-                                         key_cache, value_cache, attn_metadata.slot_mapping,
-                                         self.attn.kv_cache_dtype, self.attn._kv_scale, slabs)
-            attn_out = self.attn(q, k, v, kv_cache, attn_metadata, kv_cached=True)
+            if self._rope_in_attention(rotary_emb, value_cache.shape[3], hidden.dtype, q.shape[0]):
+                # a few sequences: rotary embedding and the cache write ride in the attention launch
+                dm = attn_metadata.decode_metadata
+                attn_out = ops.rope_paged_attention(
+                    positions, q, k, v, self.cfg.head_dim, rotary_emb.cos_sin_cache,
+                    rotary_emb.is_neox_style, key_cache, value_cache, attn_metadata.slot_mapping,
+                    self.attn.kv_cache_dtype, self.attn._kv_scale, self.hkv, self.attn.impl.scale,
+                    dm.block_tables, dm.seq_lens_tensor, dm.max_decode_seq_len,
+                    slabs=slabs, seq_order=dm.decode_seq_order,
+                    use_v1=PagedAttention.use_v1(dm.max_decode_seq_len, q.shape[0], self.hq, self.hkv))
+            else:
+                ops.rotary_reshape_and_cache(positions, q, k, v, self.cfg.head_dim,
+                                             rotary_emb.cos_sin_cache, rotary_emb.is_neox_style,
+                                             key_cache, value_cache, attn_metadata.slot_mapping,
+                                             self.attn.kv_cache_dtype, self.attn._kv_scale, slabs)
+                attn_out = self.attn(q, k, v, kv_cache, attn_metadata, kv_cached=True)
         else:
             rotary_emb(positions, q, k)     # in place on the strided views of qkv
             attn_out = self.attn(q, k, v, kv_cache, attn_metadata)
