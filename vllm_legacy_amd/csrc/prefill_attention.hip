@@ -7,41 +7,31 @@
 // + slope (j - i)) v_j, with grouped KV heads.
 //
 // One 256-thread workgroup per (128-query tile, head, sequence); wave w owns queries
-// 32w .. 32w+31 as two 16-row MFMA tiles.  Keys/values are walked in tiles of 64 staged through
-// LDS (shared by the four waves), next tile's global loads in flight during the current tile's
-// math.  Both products run on 16x16x32 MFMAs:
-//   S^T tile:  A = K   lane(g, r): key r of a 16-key block, dims 8g..8g+7 (+32 ks)   (LDS, b128)
-//              B = q^T lane(g, c): query c, the same dims                            (registers)
-//              C       lane(g, c): query c, keys 4g..4g+3
-//   O tile:    A = P   lane(g, r): query r, keys 8g..8g+7 (+32 kk)                   (LDS, b128)
-//              B = V   lane(g, c): dim 16n + c, the same keys    (LDS, two transposed b64 reads)
-//              C       lane(g, c): dim 16n + c, queries 4g..4g+3
-// so the softmax of a query is a reduction over registers and the four lanes that share c, the
-// probability tile changes lanes through a per-wave LDS tile, and V stays row-major in LDS
-// (ds_read_b64_tr_b16 delivers the column-major operand).
+// 32w .. 32w+31.  Keys/values are walked in tiles of 64 staged through LDS (shared by the four
+// waves).  Both products run on 32x32x16 MFMAs in transposed form, lane = (h, c) = (lane >> 5,
+// lane & 31):
+//   S^T tile:  A = K   lane(h, c): key c of a 32-key block, dims 16 ks + 8h .. + 7   (LDS, b128)
+//              B = q^T lane(h, c): query c, the same dims                            (registers)
+//              C       lane(h, c): query c, keys (i & 3) + 8 (i >> 2) + 4h, i = 0..15
+//   O^T tile:  A = V^T lane(h, c): dim 32n + c, keys 16 sl + 8h .. + 7
+//                      (row-major V image, two ds_read_b64_tr_b16; cached V is stored that way)
+//              B = P^T lane(h, c): query c, the same keys (registers)
+//              C       lane(h, c): query c, dims 32n + (i & 3) + 8 (i >> 2) + 4h
+// so a lane holds one query's logits, running max/sum and output column: the softmax is a
+// reduction over registers and one exchange with the partner lane (h ^ 1), rescaling needs no
+// exchange, and the probabilities go from the C layout of the first product to the B operand of
+// the second with one v_permlane32_swap per 8 keys, never through LDS.
 // Numerics: fp32 logits and running max/sum, exp values rounded to the model dtype before the
 // value product, fp32 accumulation, one division at the end.
 #include "vla_common.h"
 
 #include <math.h>
+#include <stdlib.h>
 
 namespace vla {
 namespace {
 
 constexpr int PF_BM = 128, PF_BN = 64, PF_THREADS = 256;
-
-template <class S>
-__device__ __forceinline__ f32x4 pf_mfma(u32x4 a, u32x4 b, f32x4 c);
-template <>
-__device__ __forceinline__ f32x4 pf_mfma<F16>(u32x4 a, u32x4 b, f32x4 c) {
-  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a),
-                                                __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
-}
-template <>
-__device__ __forceinline__ f32x4 pf_mfma<BF16>(u32x4 a, u32x4 b, f32x4 c) {
-  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a),
-                                                 __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
-}
 
 template <class S>
 __device__ __forceinline__ f32x16 pf_mfma32(u32x4 a, u32x4 b, f32x16 c);
@@ -91,6 +81,7 @@ struct PrefillParams {
   int log2_block_size;
   int64_t kv_block_stride, kv_head_stride;
   float kv_scale;
+  int xcd_groups;                 // heads x sequences is a multiple of 8 KV groups: XCD-aware order
 };
 
 // 16-byte chunk swizzles of the LDS images (RB bytes per row):
@@ -174,8 +165,19 @@ __global__ __launch_bounds__(PF_THREADS, D == 112 ? 1 : 2) void prefill_attentio
   // grid = (heads, sequences, query tiles): workgroups are handed out x-fastest, so all heads
   // and sequences of one query tile go together -- the heads of a KV group side by side -- and
   // the tiles with the longest key walks (the last ones) are handed out first
-  const int head = blockIdx.x, seq = blockIdx.y;
-  const int kv_head = head / (p.num_heads / p.num_kv_heads);
+  // Workgroups go to the 8 XCDs round robin in that order, and each XCD has its own L2: the
+  // heads of a KV group, which walk the same keys and values at the same time, are therefore
+  // placed 8 apart in dispatch order -- on one XCD -- and every (sequence, KV head) stream is
+  // read through a single L2, whatever the query tile.
+  int head = blockIdx.x, seq = blockIdx.y;
+  const int gsz = p.num_heads / p.num_kv_heads;
+  if (p.xcd_groups) {
+    const int r = blockIdx.x + p.num_heads * blockIdx.y;
+    const int slot = r >> 3, grp = (slot / gsz) * 8 + (r & 7);
+    seq = grp / p.num_kv_heads;
+    head = (grp % p.num_kv_heads) * gsz + slot % gsz;
+  }
+  const int kv_head = head / gsz;
   const int seq_start = p.cu_seqlens[seq];
   const int ctx = PREFIX ? p.ctx_lens[seq] : 0;
   // number of new tokens; positions are absolute: query i sits at ctx + i
@@ -247,8 +249,18 @@ __global__ __launch_bounds__(PF_THREADS, D == 112 ? 1 : 2) void prefill_attentio
   }
   const int tvl = lbs - (FP8 ? 4 : 3);                  // log2(16-byte pieces per V row of a block)
 
+#ifdef VLA_PF_STAMP   // diagnostic build: shader cycles per phase of the tile loop, summed per wave
+  uint64_t sp_load = 0, sp_stage = 0, sp_qk = 0, sp_sm = 0, sp_pv = 0;
+  uint64_t sp_tb = 0;
+  int sp_n = 0;
+  const uint64_t sp_t0 = __builtin_amdgcn_s_memtime();
+#define VLA_PF_T(v) __builtin_amdgcn_sched_barrier(0); const uint64_t v = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0)
+#else
+#define VLA_PF_T(v)
+#endif
   for (int it = 0; it < ntiles; ++it) {
     const bool pre = PREFIX && it < npre;               // workgroup-uniform
+    VLA_PF_T(ta);
     // first key of the tile (absolute position) and the end of the keys it may hold
     const int kpos0 = pre ? it * PF_BN : ctx + (it - npre) * PF_BN;
     const int limit = pre ? ctx : ctx + n_new;
@@ -321,6 +333,11 @@ __global__ __launch_bounds__(PF_THREADS, D == 112 ? 1 : 2) void prefill_attentio
         }
       }
       __syncthreads();                 // every wave is done reading the previous tile
+#ifdef VLA_PF_STAMP
+      __builtin_amdgcn_sched_barrier(0);
+      sp_tb = __builtin_amdgcn_s_memtime();
+      __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
       for (int i = 0; i < LD; ++i) {
         const int id = tid + PF_THREADS * i, row = id / CH, ch = id % CH;
@@ -331,6 +348,7 @@ __global__ __launch_bounds__(PF_THREADS, D == 112 ? 1 : 2) void prefill_attentio
       }
     }
     __syncthreads();
+    VLA_PF_T(tc);
     // wave-uniform: the wave has no query at all (a short last tile), every key follows every
     // query of this wave, or lies before all their windows
     if (q0 + 32 * wave >= n_new) continue;
@@ -353,6 +371,7 @@ __global__ __launch_bounds__(PF_THREADS, D == 112 ? 1 : 2) void prefill_attentio
                                                          16 * k_swz<DP>(row, 2 * ks + h));
         st[b] = pf_mfma32<S>(kf, qf[ks], st[b]);
       }
+    VLA_PF_T(td);
 
     // ---- online softmax of query c over this lane's 32 keys and its partner lane's, in base 2:
     // logits are scaled by scale * log2(e) so that every exponential is a bare v_exp_f32.  A
@@ -424,6 +443,7 @@ __global__ __launch_bounds__(PF_THREADS, D == 112 ? 1 : 2) void prefill_attentio
         for (int i = 0; i < 16; ++i) o[n][i] *= alpha;
     }
     m_run = m_new;
+    VLA_PF_T(te);
 
     // ---- O^T += V^T P^T, 16 keys at a time.  The B operand wants, in lane (h, c), keys
     // 16 s + 8 h .. + 7 of query c: the lane's own four keys of that group of eight and its
@@ -465,7 +485,24 @@ __global__ __launch_bounds__(PF_THREADS, D == 112 ? 1 : 2) void prefill_attentio
         o[n] = pf_mfma32<S>(vf, pf, o[n]);
       }
     }
+#ifdef VLA_PF_STAMP
+    {
+      VLA_PF_T(tf);
+      sp_load += sp_tb - ta; sp_stage += tc - sp_tb; sp_qk += td - tc; sp_sm += te - td; sp_pv += tf - te;
+      ++sp_n;
+    }
+#endif
   }
+#ifdef VLA_PF_STAMP
+  {
+    const uint64_t sp_t1 = __builtin_amdgcn_s_memtime();
+    if (lane == 0 && (blockIdx.x % 16) == 0 && blockIdx.y == 0 && (blockIdx.z % 8) == 0)
+      printf("stamppf wg %d,%d,%d wave %d tiles %d of %d total %llu issue+bar %lld wait+stage+bar %llu qk %llu softmax %llu pv %llu\n",
+             blockIdx.x, blockIdx.y, blockIdx.z, wave, sp_n, ntiles, (unsigned long long)(sp_t1 - sp_t0),
+             (long long)sp_load, (unsigned long long)sp_stage, (unsigned long long)sp_qk,
+             (unsigned long long)sp_sm, (unsigned long long)sp_pv);
+  }
+#endif
 
   // ---- normalise and store: lane (h, c) holds dims 32 n + (i & 3) + 8 (i >> 2) + 4 h of query c
   l_run += __shfl_xor(l_run, 32, 64);
@@ -496,6 +533,14 @@ namespace {
 
 bool pf_head_size_ok(int d) {
   return d == 24 || d == 64 || d == 80 || d == 96 || d == 112 || d == 128;
+}
+
+// the XCD-aware workgroup order needs whole KV groups on each of the 8 XCDs in every row of
+// heads x sequences workgroups
+int pf_xcd_groups(int num_heads, int num_kv_heads, int num_seqs) {
+  static const bool off = [] { const char* e = getenv("VLA_PF_XCD"); return e && e[0] == '0'; }();
+  const int64_t row = (int64_t)num_heads * num_seqs;
+  return !off && row % (8 * (num_heads / num_kv_heads)) == 0;
 }
 
 template <bool PREFIX, bool FP8, bool WIN>
@@ -544,6 +589,7 @@ extern "C" int vla_prefill_attention(void* out, const void* query, const void* k
   p.num_heads = num_heads; p.num_kv_heads = num_kv_heads;
   p.q_stride = query_stride; p.k_stride = key_stride; p.v_stride = value_stride;
   p.out_stride = out_stride; p.scale = scale; p.sliding_window = 0;
+  p.xcd_groups = pf_xcd_groups(num_heads, num_kv_heads, num_seqs);
   dim3 grid(num_heads, num_seqs, (max_seqlen + PF_BM - 1) / PF_BM);
   pf_launch<false, false, false>(p, head_size, dtype, grid, (hipStream_t)stream);
   VLA_HIP_CHECK(hipGetLastError());
@@ -589,6 +635,7 @@ extern "C" int vla_prefix_prefill_attention(
   p.seq_lens = seq_lens; p.ctx_lens = context_lens; p.max_blocks_per_seq = max_blocks_per_seq;
   p.log2_block_size = block_size == 8 ? 3 : block_size == 16 ? 4 : block_size == 32 ? 5 : 6;
   p.kv_block_stride = kv_block_stride; p.kv_head_stride = kv_head_stride; p.kv_scale = kv_scale;
+  p.xcd_groups = pf_xcd_groups(num_heads, num_kv_heads, num_seqs);
   dim3 grid(num_heads, num_seqs, (max_query_len + PF_BM - 1) / PF_BM);
   hipStream_t s = (hipStream_t)stream;
   if (p.sliding_window > 0) {
