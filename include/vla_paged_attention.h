@@ -68,6 +68,13 @@ int vla_set_kv_load_policy(int mode);
  * to the GEMM tolerance whichever kernel runs.  Process-wide, relaxed atomic; the environment
  * variable VLA_Q4_MID sets the initial value. */
 int vla_set_q4_row_block_kernel(int mode);
+/* No counterpart in the reference; test hook and kernel studies.  Which form of the prompt
+ * attention kernel vla_prefill_attention / vla_prefix_prefill_attention launch: 0 = by the longest
+ * prompt of the call (default), 1 = 256 threads, one 128-query tile of one head per workgroup,
+ * 2 = 512 threads, two heads of a KV group (or two query tiles) per workgroup sharing each staged
+ * K/V tile.  Results agree to the attention tolerance whichever runs.  Process-wide, relaxed
+ * atomic; the environment variable VLA_PF_FORM sets the initial value. */
+int vla_set_prefill_form(int mode);
 /* No counterpart in the reference; for measurement tooling.  Writes into buf the name of the
  * kernel instantiation a paged-attention call of this shape launches, spelled as a profiler's
  * kernel trace prints it (e.g. "pa_mfma_kernel<vla::F16, true, 128, 16, false, true, false>": model

@@ -18,6 +18,16 @@ def ops():
     return _custom_ops
 
 
+@pytest.fixture(autouse=True, params=[1, 2], ids=["wg256", "wg512"])
+def form(request, ops):
+    """Every test runs with each form of the kernel forced: the 256-thread one (a 128-query tile
+    of one head per workgroup) and the 512-thread one (two heads of a KV group, or two query
+    tiles, per workgroup); by default the longest prompt of a call picks."""
+    ops.set_prefill_form(request.param)
+    yield request.param
+    ops.set_prefill_form(0)
+
+
 def _run(ops, seq_lens, hq, hkv, d, dt, alibi, seed, strided=False):
     rng = np.random.default_rng(seed)
     t = int(sum(seq_lens))
@@ -57,6 +67,20 @@ def test_prefill_matches_oracle(ops, dt, d, heads, alibi):
 @pytest.mark.parametrize("d", [24, 80, 96, 112])
 def test_prefill_other_head_sizes(ops, dt, d):
     _run(ops, [1, 17, 64, 129, 300, 5], 4, 2, d, dt, False, seed=d)
+
+
+@pytest.mark.parametrize("heads", [(6, 2), (3, 3), (2, 1)])
+def test_prefill_group_sizes(ops, heads):
+    """odd KV group sizes and no grouping: the 512-thread form then pairs query tiles, not heads"""
+    _run(ops, [300, 1, 257, 64, 640], heads[0], heads[1], 128, O.DT_F16, False, seed=heads[0])
+
+
+@pytest.mark.parametrize("heads", [(4, 2), (2, 2)])
+def test_prefill_long_prompts(ops, heads, form):
+    """prompts long enough for the default choice of form to differ from the short tests'"""
+    if form == 2:
+        ops.set_prefill_form(0)
+    _run(ops, [3100, 100, 2177], heads[0], heads[1], 128, O.DT_F16, False, seed=11, strided=True)
 
 
 @pytest.mark.parametrize("seq_lens", [[128], [127, 129], [63, 64, 65], [1, 1, 1], [513]])

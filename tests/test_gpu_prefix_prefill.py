@@ -20,6 +20,16 @@ def ops():
     return _custom_ops
 
 
+@pytest.fixture(autouse=True, params=[1, 2], ids=["wg256", "wg512"])
+def form(request, ops):
+    """Every test runs with each form of the kernel forced (256 threads: one 128-query tile of one
+    head per workgroup; 512 threads: two heads of a KV group, or two query tiles); by default the
+    longest query run of a call picks."""
+    ops.set_prefill_form(request.param)
+    yield request.param
+    ops.set_prefill_form(0)
+
+
 def _case(seed, query_lens, ctx_lens, hq, hkv, d, bs, dt, kv_fp8, kv_scale=1.0):
     """Builds the packed new tokens and a shuffled paged cache holding each sequence's context.
     The cache is written through the oracle's reshape_and_cache, so that an fp8 cache holds what

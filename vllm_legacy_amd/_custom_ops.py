@@ -934,6 +934,12 @@ def set_q4_row_block_kernel(mode: int) -> None:
     check(_lib.lib().vla_set_q4_row_block_kernel(mode))
 
 
+def set_prefill_form(mode: int) -> None:
+    """Which form of the prompt attention kernel runs: 0 by the longest prompt of the call
+    (default), 1 the 256-thread form, 2 the 512-thread form (tests, kernel studies)."""
+    check(_lib.lib().vla_set_prefill_form(mode))
+
+
 def set_kv_load_policy(mode: int) -> None:
     """Cache policy of the attention kernel's K / V loads: 0 by size (default), 1 always
     nontemporal, 2 never.  A cache that stays resident between launches (a benchmark over a small

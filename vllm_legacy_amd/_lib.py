@@ -23,7 +23,7 @@ _lib = None
 
 EXPORTS = [
     "vla_status_string", "vla_last_hip_error", "vla_abi_version", "vla_set_attention_path",
-    "vla_set_kv_load_policy", "vla_set_q4_row_block_kernel",
+    "vla_set_kv_load_policy", "vla_set_q4_row_block_kernel", "vla_set_prefill_form",
     "vla_kv_dtype_from_string", "vla_paged_attention_v1", "vla_paged_attention_v2",
     "vla_paged_attention_v1_ordered", "vla_paged_attention_v2_ordered",
     "vla_paged_attention_v2_noalloc", "vla_paged_attention_v2_noalloc_prepare",
