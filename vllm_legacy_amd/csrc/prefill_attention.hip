@@ -255,6 +255,16 @@ __global__ __launch_bounds__(PF_THREADS, D == 112 ? 1 : 2) void prefill_attentio
   }
   const int tvl = lbs - (FP8 ? 4 : 3);                  // log2(16-byte pieces per V row of a block)
 
+  // byte offsets of this thread's pieces inside a whole tile of new tokens (the host bounds the
+  // strides)
+  uint32_t koff[LD], voff[LD];
+#pragma unroll
+  for (int i = 0; i < LD; ++i) {
+    const int id = tid + PF_THREADS * i, row = id / CH, ch = id % CH;
+    koff[i] = (uint32_t)row * (uint32_t)p.k_stride * 2u + 16u * ch;
+    voff[i] = (uint32_t)row * (uint32_t)p.v_stride * 2u + 16u * ch;
+  }
+
 #ifdef VLA_PF_STAMP   // diagnostic build: shader cycles per phase of the tile loop, summed per wave
   uint64_t sp_load = 0, sp_stage = 0, sp_qk = 0, sp_sm = 0, sp_pv = 0;
   uint64_t sp_tb = 0;
@@ -328,14 +338,27 @@ __global__ __launch_bounds__(PF_THREADS, D == 112 ? 1 : 2) void prefill_attentio
         }
       }
     } else {
-      const int kt = it - npre;
+      // a whole tile's address is scalar arithmetic plus the per-thread piece offsets; only a
+      // sequence's last, partial tile clamps rows
+      const int kt = it - npre, rows = n_new - kt * PF_BN;
+      const unsigned char* kt_base = reinterpret_cast<const unsigned char*>(kb) + (int64_t)kt * PF_BN * p.k_stride * 2;
+      const unsigned char* vt_base = reinterpret_cast<const unsigned char*>(vb) + (int64_t)kt * PF_BN * p.v_stride * 2;
+      if (rows >= PF_BN) {
 #pragma unroll
-      for (int i = 0; i < LD; ++i) {
-        const int id = tid + PF_THREADS * i, row = id / CH, ch = id % CH;
-        if (LD_EXACT || id < PF_BN * CH) {
-          const int64_t tok = min(kt * PF_BN + row, n_new - 1);
-          kreg[i] = *reinterpret_cast<const u32x4*>(kb + tok * p.k_stride + 8 * ch);
-          vreg[i] = *reinterpret_cast<const u32x4*>(vb + tok * p.v_stride + 8 * ch);
+        for (int i = 0; i < LD; ++i)
+          if (LD_EXACT || tid + PF_THREADS * i < PF_BN * CH) {
+            kreg[i] = *reinterpret_cast<const u32x4*>(kt_base + koff[i]);
+            vreg[i] = *reinterpret_cast<const u32x4*>(vt_base + voff[i]);
+          }
+      } else {
+#pragma unroll
+        for (int i = 0; i < LD; ++i) {
+          const int id = tid + PF_THREADS * i, row = id / CH, ch = id % CH;
+          if (LD_EXACT || id < PF_BN * CH) {
+            const int64_t tok = min(row, rows - 1);
+            kreg[i] = *reinterpret_cast<const u32x4*>(kt_base + tok * p.k_stride * 2 + 16 * ch);
+            vreg[i] = *reinterpret_cast<const u32x4*>(vt_base + tok * p.v_stride * 2 + 16 * ch);
+          }
         }
       }
       __syncthreads();                 // every wave is done reading the previous tile
