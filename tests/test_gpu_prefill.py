@@ -75,6 +75,14 @@ def test_prefill_group_sizes(ops, heads):
     _run(ops, [300, 1, 257, 64, 640], heads[0], heads[1], 128, O.DT_F16, False, seed=heads[0])
 
 
+@pytest.mark.parametrize("case", [((8, 2), [32, 7, 1, 20]), ((8, 2), [64, 33, 50]), ((8, 1), [16, 31]),
+                                  ((6, 3), [30, 64]), ((4, 4), [20, 5])])
+@pytest.mark.parametrize("d", [128, 64])
+def test_prefill_short_prompts_share_tiles(ops, case, d):
+    """prompts of at most 64 / 32 tokens: 2 / 4 heads of a KV group per 128-row tile (256-thread form)"""
+    _run(ops, case[1], case[0][0], case[0][1], d, O.DT_BF16, case[0][0] == 6, seed=d + len(case[1]))
+
+
 @pytest.mark.parametrize("heads", [(4, 2), (2, 2)])
 def test_prefill_long_prompts(ops, heads, form):
     """prompts long enough for the default choice of form to differ from the short tests'"""

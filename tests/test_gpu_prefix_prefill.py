@@ -141,6 +141,23 @@ def test_prefix_head_size_24_needs_a_16_bit_cache(ops):
     assert st == 1          # VLA_ERR_HEAD_SIZE
 
 
+@pytest.mark.parametrize("case", [
+    (8, 2, [32, 7, 1, 20], [300, 64, 129, 0]),      # runs of <= 32 tokens, groups of 4: four heads per tile
+    (8, 2, [64, 33, 50], [200, 17, 640]),           # <= 64 tokens: two heads per tile
+    (8, 1, [16, 31], [257, 100]),                   # groups of 8
+    (6, 3, [30, 64], [90, 70]),                     # groups of 2
+    (4, 4, [20, 5], [100, 260]),                    # no grouping: one head per tile
+])
+@pytest.mark.parametrize("kv_fp8", [False, True])
+@pytest.mark.parametrize("window", [0, 48])
+def test_prefix_short_query_runs(ops, case, kv_fp8, window):
+    """A chunk of a prompt (or a few tokens to verify) behind a cached prefix: the 256-thread form
+    packs 2 or 4 heads of a KV group into one 128-row tile."""
+    hq, hkv, ql, cl = case
+    _run(ops, hq + len(ql) + window, ql, cl, hq, hkv, 128, 16, O.DT_F16, kv_fp8=kv_fp8, window=window,
+         alibi=(hq == 6))
+
+
 @pytest.mark.parametrize("bs", [8, 64])
 def test_prefix_other_block_sizes(ops, bs):
     _run(ops, bs, [33, 5, 130], [70, 129, 8], 4, 1, 128, bs, O.DT_F16)

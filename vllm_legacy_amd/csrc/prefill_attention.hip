@@ -88,6 +88,7 @@ struct PrefillParams {
   float kv_scale;
   int xcd_groups;                 // heads x sequences is a multiple of 8 KV groups: XCD-aware order
   int pair_heads;                 // 512-thread form: a workgroup takes two heads of a KV group
+  int heads_per_tile;             // 256-thread form: 1, 2 or 4 heads of a KV group share a tile
 };
 
 // 16-byte chunk swizzles of the LDS images (RB bytes per row):
@@ -175,20 +176,26 @@ __global__ __launch_bounds__(PF_THREADS, D == 112 ? 1 : 2) void prefill_attentio
   // heads of a KV group, which walk the same keys and values at the same time, are therefore
   // placed 8 apart in dispatch order -- on one XCD -- and every (sequence, KV head) stream is
   // read through a single L2, whatever the query tile.
-  int head = blockIdx.x, seq = blockIdx.y;
-  const int gsz = p.num_heads / p.num_kv_heads;
+  // Short query runs (a chunk of a prompt behind a long cached prefix, a few tokens to verify):
+  // 2 or 4 heads of a KV group share the 128-row tile, 64 or 32 queries each, instead of leaving
+  // half or three quarters of its waves without queries (p.heads_per_tile).
+  const int hpt = p.heads_per_tile, seg_rows = PF_BM / hpt, wps = 4 / hpt;
+  int hw = blockIdx.x, seq = blockIdx.y;
+  const int gsz = p.num_heads / p.num_kv_heads, gx = gsz / hpt;
   if (p.xcd_groups) {
-    const int r = blockIdx.x + p.num_heads * blockIdx.y;
-    const int slot = r >> 3, grp = (slot / gsz) * 8 + (r & 7);
+    const int r = blockIdx.x + gridDim.x * blockIdx.y;
+    const int slot = r >> 3, grp = (slot / gx) * 8 + (r & 7);
     seq = grp / p.num_kv_heads;
-    head = (grp % p.num_kv_heads) * gsz + slot % gsz;
+    hw = (grp % p.num_kv_heads) * gx + slot % gx;
   }
+  const int head = hw * hpt + wave / wps;
+  const int wrow = 32 * (wave % wps);        // this wave's first query inside its head's rows
   const int kv_head = head / gsz;
   const int seq_start = p.cu_seqlens[seq];
   const int ctx = PREFIX ? p.ctx_lens[seq] : 0;
   // number of new tokens; positions are absolute: query i sits at ctx + i
   const int n_new = PREFIX ? p.seq_lens[seq] - ctx : p.cu_seqlens[seq + 1] - seq_start;
-  const int q0 = (gridDim.z - 1 - blockIdx.z) * PF_BM;
+  const int q0 = (gridDim.z - 1 - blockIdx.z) * seg_rows;
   if (q0 >= n_new) return;
   // a window known to be absent at compile time keeps its tests out of the tile loop (5 % of
   // the kernel's time when left to run time)
@@ -201,7 +208,7 @@ __global__ __launch_bounds__(PF_THREADS, D == 112 ? 1 : 2) void prefill_attentio
   // ---- query fragments: lane (h, c) holds dims 16 s + 8 h .. + 7 of query c; rows past the
   // sequence are clamped (their results are never stored)
   u32x4 qf[KS];
-  const int qrow = q0 + 32 * wave + c;
+  const int qrow = q0 + wrow + c;
   const int qpos = ctx + qrow;
   {
     const T* qp = qb + (int64_t)min(qrow, n_new - 1) * p.q_stride;
@@ -220,7 +227,7 @@ __global__ __launch_bounds__(PF_THREADS, D == 112 ? 1 : 2) void prefill_attentio
   const float scale2 = p.scale * kLog2e;
   const float slope2 = p.alibi_slopes ? p.alibi_slopes[head] * kLog2e : 0.f;
   // positions of this wave's first and last query
-  const int wq_min = ctx + q0 + 32 * wave, wq_max = wq_min + 31;
+  const int wq_min = ctx + q0 + wrow, wq_max = wq_min + 31;
 
   // O^T accumulators: lane (h, c) holds dims 32 n + (i & 3) + 8 (i >> 2) + 4 h of query c
   f32x16 o[ND];
@@ -238,7 +245,7 @@ __global__ __launch_bounds__(PF_THREADS, D == 112 ? 1 : 2) void prefill_attentio
   // block; cached K lands row-major (row = key) like new keys, cached V as it is stored
   // (row = dim).
   const int npre = PREFIX ? (ctx + PF_BN - 1) / PF_BN : 0;
-  const int ntiles = npre + (min(n_new, q0 + PF_BM) + PF_BN - 1) / PF_BN;
+  const int ntiles = npre + (min(n_new, q0 + seg_rows) + PF_BN - 1) / PF_BN;
   const int lbs = PREFIX ? p.log2_block_size : 0, BS = 1 << lbs;
   const int* bt = PREFIX ? p.block_tables + (int64_t)seq * p.max_blocks_per_seq : nullptr;
   const int last_blk = ctx > 0 ? (ctx - 1) >> lbs : 0;
@@ -380,7 +387,7 @@ __global__ __launch_bounds__(PF_THREADS, D == 112 ? 1 : 2) void prefill_attentio
     VLA_PF_T(tc);
     // wave-uniform: the wave has no query at all (a short last tile), every key follows every
     // query of this wave, or lies before all their windows
-    if (q0 + 32 * wave >= n_new) continue;
+    if (q0 + wrow >= n_new) continue;
     if (kpos0 > wq_max) continue;
     if (W > 0 && wq_min - (kpos0 + PF_BN - 1) >= W) continue;
 
@@ -1084,8 +1091,12 @@ void pf_launch(PrefillParams p, int head_size, int dtype, int num_seqs, int max_
     const int bm = p.pair_heads ? PF_BM : 2 * PF_BM;
     grid = dim3(p.num_heads / hx, num_seqs, (max_len + bm - 1) / bm);
   } else {
-    p.xcd_groups = pf_xcd_groups(p.num_heads, gsz, num_seqs);
-    grid = dim3(p.num_heads, num_seqs, (max_len + PF_BM - 1) / PF_BM);
+    // query runs of at most 64 / 32 tokens: two / four heads of a KV group per 128-row tile
+    const int hpt = (max_len <= PF_BM / 4 && gsz % 4 == 0) ? 4 : (max_len <= PF_BM / 2 && gsz % 2 == 0) ? 2 : 1;
+    p.heads_per_tile = hpt;
+    p.xcd_groups = pf_xcd_groups(p.num_heads / hpt, gsz / hpt, num_seqs);
+    const int rows = PF_BM / hpt;
+    grid = dim3(p.num_heads / hpt, num_seqs, (max_len + rows - 1) / rows);
   }
 #define VLA_PF(ST, DD)                                                                       \
   do {                                                                                       \
