@@ -21,6 +21,11 @@
 // reduction over registers and one exchange with the partner lane (h ^ 1), rescaling needs no
 // exchange, and the probabilities go from the C layout of the first product to the B operand of
 // the second with one v_permlane32_swap per 8 keys, never through LDS.
+// Two forms share that arithmetic: prefill_attention_kernel (256 threads as above, two workgroups
+// per CU; short query runs pack 2 or 4 heads of a KV group into the tile) and
+// prefill_attention_il_kernel (512 threads: two such sub-tiles share every staged K/V tile, one
+// workgroup per CU, the tile loop one tile ahead on the key side); the launcher picks by shape
+// (pf_use_il), vla_set_prefill_form overrides.
 // Numerics: fp32 logits and running max/sum, exp values rounded to the model dtype before the
 // value product, fp32 accumulation, one division at the end.
 #include "vla_common.h"
