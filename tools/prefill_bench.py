@@ -10,8 +10,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from vllm_legacy_amd import _custom_ops as ops  # noqa: E402
 
 
-def timed(fn, iters=9, warmup=3):
-    # three untimed launches first: the first timed ones otherwise run 10-20 % slow (clock ramp)
+def timed(fn, iters=15, warmup=10):
+    # untimed launches first: the first ones of a process run 10-20 % slow (clock ramp)
     for _ in range(warmup):
         fn()
     torch.cuda.synchronize()
