@@ -242,8 +242,10 @@ def test_gptq_linear_method_llama70b_tp8_shapes(ops, k, n, m):
 # The unsliced 128-row launches (128 x 64 wave tiles, two K parts per workgroup) at their edges:
 # a last column tile that is partly outside the matrix, a last row tile of 44 rows, 64-deep
 # groups, and the GPTQ zero convention (stored zero - 1).
+# ... and a wide layer at 33..64 rows (64-row tiles: two K slices of two K parts).
 @pytest.mark.parametrize("kind,m,k,n,group", [("awq", 300, 4096, 16456, 64), ("awq", 129, 2048, 28680, 128),
-                                              ("gptq", 256, 4096, 28672, 128)])
+                                              ("gptq", 256, 4096, 28672, 128), ("awq", 48, 4096, 28672, 128),
+                                              ("gptq", 64, 4096, 24584, 128)])
 def test_unsliced_wide_layers_at_tile_edges(ops, kind, m, k, n, group):
     rng = np.random.default_rng(m + n)
     x = O.to_bits(rng.uniform(-1, 1, (m, k)).astype(np.float32), O.DT_F16)
